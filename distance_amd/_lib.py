@@ -1,0 +1,87 @@
+"""ctypes loader for libdistance_hip.so (the C ABI in include/distance_hip.h).
+
+There is no CPU fallback and no torch dependency here: if the HIP library is missing this module
+raises, and every device call fails with a DistanceError when HIP does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdistance_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "distance_hip.h")
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+
+class DistanceError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[dst status {status}] {message}")
+        self.status = status
+        self.message = message
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/distance_hip.h declares (used by the CPU symbol-export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dst_[a-z0-9_]+)\s*\(", text)))
+
+
+_SIGS = {
+    "dst_abi_version": (C.c_int, []),
+    "dst_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dst_measure_from_name": (C.c_int, [C.c_char_p]),
+    "dst_tally_width": (C.c_int, [C.c_int]),
+    "dst_status_string": (C.c_char_p, [C.c_int]),
+    "dst_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "dst_destroy": (C.c_int, [_vp]),
+    "dst_last_error": (C.c_char_p, [_vp]),
+    "dst_set_scratch_limit": (C.c_int, [_vp, C.c_size_t]),
+    "dst_set_variant": (C.c_int, [_vp, C.c_int]),
+    "dst_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
+    "dst_upload_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
+    "dst_set_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "dst_get_base_counts": (C.c_int, [_vp, C.c_int, _vp]),
+    "dst_square_pairs": (C.c_uint64, [C.c_uint64]),
+    "dst_square_row_start": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "dst_partition_square": (C.c_int, [C.c_uint64, C.c_int, _u64p]),
+    "dst_partition_rect": (C.c_int, [C.c_uint64, C.c_int, _u64p]),
+    "dst_run_square": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t, _vp]),
+    "dst_run_rect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
+                               C.c_size_t, _vp]),
+    "dst_run_square_host": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t]),
+    "dst_run_rect_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
+                                    C.c_size_t]),
+    "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),
+    "dst_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "dst_plan_tiles": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp,
+                                 C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dst_finalize": (C.c_int, [C.c_int, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dst_format_distance": (C.c_int, [C.c_int, C.c_double, C.c_int64, C.c_char_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  distance_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,609 @@
+// dst_api.cpp — the GPU-facing half of the C ABI (include/distance_hip.h): context, upload,
+// run.  One context = one GPU = one owner thread.  No CPU fallback: every entry point that needs
+// the device fails with DST_ERR_HIP when HIP does.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "dst_internal.h"
+
+using namespace dst;
+
+struct dst_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceSet set[2];
+    // staging for host uploads / unaligned device inputs
+    uint8_t *stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned long long *d_first_bad = nullptr;
+    // tally scratch of the two-pass (tally -> finalize) float path
+    uint32_t *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    size_t scratch_limit = (size_t)32 << 30;
+    // tile list cache
+    BlockDesc *d_blocks = nullptr;
+    size_t blocks_cap = 0;
+    struct {
+        bool valid = false, square = false;
+        uint64_t rb = 0, re = 0, ncols = 0;
+        int bm = 0, bn = 0;
+        uint32_t nblocks = 0;
+    } bkey;
+    int variant = 0;
+    hipEvent_t ev[6] = {};
+    float pair_ms = 0, fin_ms = 0, pack_ms = 0;
+    bool timed_pair = false, timed_fin = false, timed_pack = false;
+    std::string err;
+};
+
+namespace {
+
+std::string g_create_err;
+std::mutex g_create_mu;
+
+int fail(dst_ctx *ctx, int status, const std::string &msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    return status;
+}
+
+int fail_hip(dst_ctx *ctx, hipError_t e, const char *what)
+{
+    return fail(ctx, e == hipErrorOutOfMemory ? DST_ERR_NOMEM : DST_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                       \
+    do {                                         \
+        hipError_t e_ = (call);                  \
+        if (e_ != hipSuccess)                    \
+            return fail_hip((ctx), e_, #call);   \
+    } while (0)
+
+int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
+{
+    if (*have >= want)
+        return DST_OK;
+    if (*ptr) {
+        HIP_TRY(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(ptr, want));
+    *have = want;
+    return DST_OK;
+}
+
+void free_set(DeviceSet &s)
+{
+    if (s.planes)
+        (void)hipFree(s.planes);
+    if (s.counts)
+        (void)hipFree(s.counts);
+    s = DeviceSet{};
+}
+
+// (re)allocate the planes / counts of a set for n x len
+int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
+{
+    const size_t nchunks = (len + kChunkSites - 1) / kChunkSites;
+    const size_t npad = ((n + 256 + kPadRecords - 1) / kPadRecords) * kPadRecords;
+    const size_t bytes = (size_t)PL_COUNT * nchunks * npad * sizeof(uint4);
+    if (!s.planes || s.planes_bytes < bytes || s.npad != npad || s.nchunks != nchunks) {
+        free_set(s);
+        HIP_TRY(ctx, hipMalloc((void **)&s.planes, bytes ? bytes : 16));
+        s.planes_bytes = bytes;
+        HIP_TRY(ctx, hipMalloc((void **)&s.counts, npad * 4 * sizeof(uint32_t)));
+    }
+    s.n = n;
+    s.len = len;
+    s.nchunks = nchunks;
+    s.npad = npad;
+    s.loaded = false;
+    s.have_counts = false;
+    return DST_OK;
+}
+
+int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, size_t len,
+                     size_t row_stride, const uint32_t *d_counts, hipStream_t stream)
+{
+    DeviceSet &s = ctx->set[slot];
+    int rc = shape_set(ctx, s, n, len);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_bad, 0xFF, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], stream));
+    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, ctx->d_first_bad, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], stream));
+    ctx->timed_pack = true;
+    if (d_counts) {
+        HIP_TRY(ctx, hipMemsetAsync(s.counts, 0, s.npad * 4 * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s.counts, d_counts, n * 4 * sizeof(uint32_t),
+                                    hipMemcpyDeviceToDevice, stream));
+        s.have_counts = true;
+    }
+    unsigned long long first_bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof first_bad, hipMemcpyDeviceToHost,
+                                stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (first_bad != ~0ull) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg,
+                      "invalid nucleotide code in record %llu at site %llu (not a value src/encoding.rs produces)",
+                      first_bad / (len ? len : 1), first_bad % (len ? len : 1));
+        return fail(ctx, DST_ERR_INVALID_CODE, msg);
+    }
+    s.loaded = true;
+    ctx->bkey.valid = false;
+    return DST_OK;
+}
+
+int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
+{
+    if (s.have_counts)
+        return DST_OK;
+    HIP_TRY(ctx, launch_fill_counts(s, stream));
+    s.have_counts = true;
+    return DST_OK;
+}
+
+int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t ncols, TileShape ts,
+                   hipStream_t stream, uint32_t *nblocks)
+{
+    auto &k = ctx->bkey;
+    if (k.valid && k.square == square && k.rb == rb && k.re == re && k.ncols == ncols &&
+        k.bm == ts.bm && k.bn == ts.bn) {
+        *nblocks = k.nblocks;
+        return DST_OK;
+    }
+    std::vector<BlockDesc> blocks = build_blocks(square, rb, re, ncols, ts);
+    const size_t bytes = blocks.size() * sizeof(BlockDesc);
+    if (bytes > ctx->blocks_cap) {
+        // the previous list may still be read by an in-flight kernel on this stream
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (ctx->d_blocks)
+            HIP_TRY(ctx, hipFree(ctx->d_blocks));
+        ctx->d_blocks = nullptr;
+        ctx->blocks_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, bytes));
+        ctx->blocks_cap = bytes;
+    }
+    if (bytes) {
+        // synchronous copy from pageable memory; ordered after prior work on `stream`
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_blocks, blocks.data(), bytes, hipMemcpyHostToDevice));
+    }
+    k.valid = true;
+    k.square = square;
+    k.rb = rb;
+    k.re = re;
+    k.ncols = ncols;
+    k.bm = ts.bm;
+    k.bn = ts.bn;
+    k.nblocks = (uint32_t)blocks.size();
+    *nblocks = k.nblocks;
+    return DST_OK;
+}
+
+// the common run: rows [rb, re) of `rows` against every (square: later) record of `cols`
+int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot, uint64_t rb,
+               uint64_t re, int out_kind, void *d_out, size_t cap, void *stream_v)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (measure < DST_N || measure > DST_TN93)
+        return fail(ctx, DST_ERR_ARG, "unknown measure");
+    if (out_kind != DST_OUT_DISTANCE && out_kind != DST_OUT_TALLY)
+        return fail(ctx, DST_ERR_ARG, "unknown output kind");
+    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    DeviceSet &rows = ctx->set[row_slot];
+    DeviceSet &cols = ctx->set[col_slot];
+    if (!rows.loaded || !cols.loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    if (rows.len != cols.len) {
+        char msg[128];  // src/fastaio.rs:93-95
+        std::snprintf(msg, sizeof msg, "Different length sequences in alignment(s): %zu vs %zu", rows.len,
+                      cols.len);
+        return fail(ctx, DST_ERR_STATE, msg);
+    }
+    if (rb > re || re > rows.n)
+        return fail(ctx, DST_ERR_ARG, "row range out of bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const uint64_t total_pairs = pairs_in_rows(square, cols.n, rb, re);
+    const size_t need = dst_out_bytes(measure, out_kind, total_pairs);
+    if (need > cap)
+        return fail(ctx, DST_ERR_CAPACITY, "output buffer too small for the requested rows");
+    ctx->timed_pair = ctx->timed_fin = false;
+    ctx->pair_ms = ctx->fin_ms = 0;
+    if (total_pairs == 0)
+        return DST_OK;
+    if (!d_out)
+        return fail(ctx, DST_ERR_ARG, "null output pointer");
+
+    const int width = tally_width(measure);
+    const bool direct = out_kind == DST_OUT_TALLY || measure_is_int(measure);
+    if (measure == DST_TN93 && out_kind == DST_OUT_DISTANCE) {
+        int rc = need_counts(ctx, rows, stream);
+        if (!rc && &cols != &rows)
+            rc = need_counts(ctx, cols, stream);
+        if (rc)
+            return rc;
+    }
+    const TileShape ts = tile_shape(measure, ctx->variant);
+    const uint64_t out_base = square ? square_row_start(cols.n, rb) : 0;
+
+    // float distances go tally -> scratch -> finalize; cut rows into slabs whose tallies fit
+    uint64_t max_pairs = ~0ull;
+    if (!direct) {
+        const size_t per_pair = (size_t)width * sizeof(uint32_t);
+        const size_t want = std::min((size_t)total_pairs * per_pair, ctx->scratch_limit);
+        size_t have = ctx->scratch_bytes;
+        if (have < want) {
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            int rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes, want);
+            if (rc)
+                return rc;
+        }
+        max_pairs = std::max<uint64_t>(ctx->scratch_bytes / per_pair, 1);
+    }
+
+    bool first = true;
+    for (uint64_t sb = rb; sb < re;) {
+        const uint64_t se = slab_end(square, cols.n, sb, re, max_pairs);
+        const uint64_t slab_pairs = pairs_in_rows(square, cols.n, sb, se);
+        if (!direct && slab_pairs * width * sizeof(uint32_t) > ctx->scratch_bytes) {
+            // one row alone exceeds the scratch: grow it (rows are the slab granule)
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            int rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes,
+                                  (size_t)slab_pairs * width * sizeof(uint32_t));
+            if (rc)
+                return rc;
+        }
+        uint32_t nblocks = 0;
+        int rc = prepare_blocks(ctx, square, sb, se, cols.n, ts, stream, &nblocks);
+        if (rc)
+            return rc;
+        const uint64_t slab_base = square ? square_row_start(cols.n, sb) : (sb - rb) * cols.n;
+        const uint64_t slab_off = square ? slab_base - out_base : slab_base;  // pairs before the slab
+        PairLaunch pl{};
+        pl.rows = &rows;
+        pl.cols = &cols;
+        pl.square = square;
+        pl.row_begin = sb;
+        pl.row_end = se;
+        pl.out_base = square ? slab_base : 0;
+        pl.d_blocks = ctx->d_blocks;
+        pl.nblocks = nblocks;
+        if (direct) {
+            if (out_kind == DST_OUT_TALLY)
+                pl.d_tallies = (uint32_t *)d_out + slab_off * width;
+            else
+                pl.d_int_out = (int64_t *)d_out + slab_off;
+        } else {
+            pl.d_tallies = ctx->scratch;
+        }
+        if (nblocks) {
+            if (first)
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+            HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+            ctx->timed_pair = true;
+            if (!direct) {
+                if (first)
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+                HIP_TRY(ctx, launch_finalize(measure, pl, (double *)d_out + slab_off, stream));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+                ctx->timed_fin = true;
+            }
+            first = false;
+        }
+        sb = se;
+    }
+    if (!stream_v)
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return DST_OK;
+}
+
+int run_host(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot, uint64_t rb,
+             uint64_t re, int out_kind, void *h_out, size_t cap)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    const DeviceSet &cols = ctx->set[col_slot];
+    const uint64_t pairs = pairs_in_rows(square, cols.n, rb, re);
+    const size_t bytes = dst_out_bytes(measure, out_kind, pairs);
+    if (bytes > cap)
+        return fail(ctx, DST_ERR_CAPACITY, "output buffer too small for the requested rows");
+    if (bytes == 0)
+        return run_common(ctx, measure, square, row_slot, col_slot, rb, re, out_kind, nullptr, 0, nullptr);
+    if (!h_out)
+        return fail(ctx, DST_ERR_ARG, "null output pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_out, bytes));
+    int rc = run_common(ctx, measure, square, row_slot, col_slot, rb, re, out_kind, d_out, bytes, nullptr);
+    if (rc == DST_OK) {
+        hipError_t e = hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail_hip(ctx, e, "hipMemcpy(D2H results)");
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dst_device_count(int *count)
+{
+    if (!count)
+        return DST_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return DST_ERR_HIP;
+    }
+    *count = n;
+    return DST_OK;
+}
+
+const char *dst_last_error(const dst_ctx *ctx)
+{
+    if (ctx)
+        return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_create_mu);
+    return g_create_err.c_str();
+}
+
+int dst_create(int device, dst_ctx **out)
+{
+    if (!out)
+        return DST_ERR_ARG;
+    *out = nullptr;
+    auto bail = [&](dst_ctx *c, hipError_t e, const char *what) {
+        std::lock_guard<std::mutex> lk(g_create_mu);
+        g_create_err = std::string(what) + ": " + hipGetErrorString(e);
+        delete c;
+        return e == hipErrorOutOfMemory ? DST_ERR_NOMEM : DST_ERR_HIP;
+    };
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return bail(nullptr, e != hipSuccess ? e : hipErrorNoDevice,
+                    "no HIP device (libdistance_hip has no CPU path)");
+    if (device < 0 || device >= count) {
+        std::lock_guard<std::mutex> lk(g_create_mu);
+        g_create_err = "device index out of range";
+        return DST_ERR_ARG;
+    }
+    dst_ctx *c = new (std::nothrow) dst_ctx;
+    if (!c)
+        return DST_ERR_NOMEM;
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return bail(c, e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(c, e, "hipStreamCreate");
+    for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess)
+            return bail(c, e, "hipEventCreate");
+    if ((e = hipMalloc((void **)&c->d_first_bad, sizeof(unsigned long long))) != hipSuccess)
+        return bail(c, e, "hipMalloc");
+    *out = c;
+    return DST_OK;
+}
+
+int dst_destroy(dst_ctx *ctx)
+{
+    if (!ctx)
+        return DST_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_set(ctx->set[0]);
+    free_set(ctx->set[1]);
+    if (ctx->stage)
+        (void)hipFree(ctx->stage);
+    if (ctx->scratch)
+        (void)hipFree(ctx->scratch);
+    if (ctx->d_blocks)
+        (void)hipFree(ctx->d_blocks);
+    if (ctx->d_first_bad)
+        (void)hipFree(ctx->d_first_bad);
+    for (auto &ev : ctx->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DST_OK;
+}
+
+int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes)
+{
+    if (!ctx || bytes < 1024)
+        return DST_ERR_ARG;
+    ctx->scratch_limit = bytes;
+    if (ctx->scratch_bytes > bytes) {  // shrink now so the new limit is what runs see
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    return DST_OK;
+}
+
+int dst_set_variant(dst_ctx *ctx, int variant)
+{
+    if (!ctx || variant < 0)
+        return DST_ERR_ARG;
+    ctx->variant = variant;
+    ctx->bkey.valid = false;
+    return DST_OK;
+}
+
+int dst_upload(dst_ctx *ctx, int slot, const uint8_t *codes, size_t n, size_t len, size_t row_stride,
+               const uint32_t *base_counts)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (slot < 0 || slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    if (n == 0)
+        return fail(ctx, DST_ERR_ARG, "Empty FASTA file");  // src/fastaio.rs:97-99
+    if (!codes || row_stride < len)
+        return fail(ctx, DST_ERR_ARG, "null codes or row_stride < len");
+    if (n >= 0xFFFFFE00ull || len >= 0xFFFFFF00ull)
+        return fail(ctx, DST_ERR_ARG, "n and len must fit 32 bits");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // pitched staging copy: rows land 128-byte aligned whatever the caller's stride
+    const size_t pitch = ((len + 127) / 128) * 128;
+    const size_t want = std::max<size_t>(pitch * n, 128) + (base_counts ? n * 16 : 0);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = ensure_bytes(ctx, (void **)&ctx->stage, &ctx->stage_bytes, want);
+    if (rc)
+        return rc;
+    if (len)
+        HIP_TRY(ctx, hipMemcpy2DAsync(ctx->stage, pitch, codes, row_stride, len, n, hipMemcpyHostToDevice,
+                                      ctx->stream));
+    uint32_t *d_counts = nullptr;
+    if (base_counts) {
+        d_counts = reinterpret_cast<uint32_t *>(ctx->stage + std::max<size_t>(pitch * n, 128));
+        HIP_TRY(ctx, hipMemcpyAsync(d_counts, base_counts, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return pack_from_device(ctx, slot, ctx->stage, n, len, pitch, d_counts, ctx->stream);
+}
+
+int dst_upload_device(dst_ctx *ctx, int slot, const void *d_codes, size_t n, size_t len,
+                      size_t row_stride, const uint32_t *d_base_counts, void *stream_v)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (slot < 0 || slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    if (n == 0)
+        return fail(ctx, DST_ERR_ARG, "Empty FASTA file");
+    if (!d_codes || row_stride < len)
+        return fail(ctx, DST_ERR_ARG, "null codes or row_stride < len");
+    if (n >= 0xFFFFFE00ull || len >= 0xFFFFFF00ull)
+        return fail(ctx, DST_ERR_ARG, "n and len must fit 32 bits");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    return pack_from_device(ctx, slot, (const uint8_t *)d_codes, n, len, row_stride, d_base_counts, stream);
+}
+
+int dst_set_info(const dst_ctx *ctx, int slot, size_t *n, size_t *len)
+{
+    if (!ctx || slot < 0 || slot > 1)
+        return DST_ERR_ARG;
+    if (!ctx->set[slot].loaded)
+        return DST_ERR_STATE;
+    if (n)
+        *n = ctx->set[slot].n;
+    if (len)
+        *len = ctx->set[slot].len;
+    return DST_OK;
+}
+
+int dst_get_base_counts(dst_ctx *ctx, int slot, uint32_t *counts)
+{
+    if (!ctx || slot < 0 || slot > 1 || !counts)
+        return DST_ERR_ARG;
+    DeviceSet &s = ctx->set[slot];
+    if (!s.loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = need_counts(ctx, s, ctx->stream);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(counts, s.counts, s.n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DST_OK;
+}
+
+int dst_run_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,
+                   void *d_out, size_t cap, void *stream)
+{
+    return run_common(ctx, measure, true, 0, 0, row_begin, row_end, out_kind, d_out, cap, stream);
+}
+
+int dst_run_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
+                 uint64_t row_end, int out_kind, void *d_out, size_t cap, void *stream)
+{
+    return run_common(ctx, measure, false, row_slot, col_slot, row_begin, row_end, out_kind, d_out, cap,
+                      stream);
+}
+
+int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,
+                        void *h_out, size_t cap)
+{
+    return run_host(ctx, measure, true, 0, 0, row_begin, row_end, out_kind, h_out, cap);
+}
+
+int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
+                      uint64_t row_end, int out_kind, void *h_out, size_t cap)
+{
+    return run_host(ctx, measure, false, row_slot, col_slot, row_begin, row_end, out_kind, h_out, cap);
+}
+
+int dst_plan_tiles(int square, uint64_t row_begin, uint64_t row_end, uint64_t n_cols, int measure,
+                   int variant, uint32_t *ij, size_t cap_tiles, size_t *count, int *tile_rows,
+                   int *tile_cols)
+{
+    if (measure < DST_N || measure > DST_TN93 || !count)
+        return DST_ERR_ARG;
+    const TileShape ts = tile_shape(measure, variant);
+    if (tile_rows)
+        *tile_rows = ts.bm;
+    if (tile_cols)
+        *tile_cols = ts.bn;
+    const std::vector<BlockDesc> blocks = build_blocks(square != 0, row_begin, row_end, n_cols, ts);
+    *count = blocks.size();
+    if (!ij)
+        return DST_OK;
+    if (cap_tiles < blocks.size())
+        return DST_ERR_CAPACITY;
+    for (size_t k = 0; k < blocks.size(); ++k) {
+        ij[2 * k] = blocks[k].i0;
+        ij[2 * k + 1] = blocks[k].j0;
+    }
+    return DST_OK;
+}
+
+int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *pack_ms)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->timed_pair) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pair_ms, ctx->ev[0], ctx->ev[1]));
+    }
+    if (ctx->timed_fin) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->fin_ms, ctx->ev[2], ctx->ev[3]));
+    }
+    if (ctx->timed_pack) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pack_ms, ctx->ev[4], ctx->ev[5]));
+    }
+    if (pair_ms)
+        *pair_ms = ctx->pair_ms;
+    if (finalize_ms)
+        *finalize_ms = ctx->fin_ms;
+    if (pack_ms)
+        *pack_ms = ctx->pack_ms;
+    return DST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// dst_host.cpp — host-side logic of the engine that needs no GPU: canonical pair order and its
+// partition (src/lib.rs:502-596), tile scheduling, finalisation in the reference's f64 operation
+// order (src/measures.rs) and the TSV number format (src/lib.rs:626-633).
+// Built with -ffp-contract=off: rustc never contracts a*b+c, and ln/sqrt are glibc's in both.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "dst_internal.h"
+
+namespace dst {
+
+int tally_width(int measure)
+{
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH: return 1;
+    case DST_RAW:
+    case DST_JC69: return 2;
+    case DST_K80: return 3;
+    case DST_TN93: return 4;
+    default: return 0;
+    }
+}
+
+bool measure_is_int(int measure) { return measure == DST_N || measure == DST_N_HIGH; }
+
+// index of pair (i, i+1) in the i<j row-major enumeration of generate_pairs_square (lib.rs:511-512)
+uint64_t square_row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
+
+uint64_t pairs_in_rows(bool square, uint64_t n_cols, uint64_t row_begin, uint64_t row_end)
+{
+    if (row_end <= row_begin)
+        return 0;
+    if (!square)
+        return (row_end - row_begin) * n_cols;
+    const uint64_t e = std::min(row_end, n_cols);
+    const uint64_t b = std::min(row_begin, e);
+    return square_row_start(n_cols, e) - square_row_start(n_cols, b);
+}
+
+uint64_t slab_end(bool square, uint64_t n_cols, uint64_t row_begin, uint64_t row_end,
+                  uint64_t max_pairs)
+{
+    if (pairs_in_rows(square, n_cols, row_begin, row_end) <= max_pairs)
+        return row_end;
+    uint64_t lo = row_begin + 1, hi = row_end;  // invariant: rows [row_begin, lo) always accepted
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (pairs_in_rows(square, n_cols, row_begin, mid) <= max_pairs)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+// Tiles of one launch.  A column tile ("panel") of BN records is shared by every row tile that
+// meets it; the panel is the big operand (BN >> BM), so all row tiles of one panel are queued
+// back to back on ONE of 8 queues, and the queues are interleaved so that block ids b, b+8, ...
+// (observed to land on one XCD: MI355X_MICROARCH.md "Workgroup dispatch") drain one queue.
+// Placement only affects speed (L2 hits on the panel), never results.
+std::vector<BlockDesc> build_blocks(bool square, uint64_t row_begin, uint64_t row_end,
+                                    uint64_t n_cols, TileShape ts)
+{
+    constexpr int kQueues = 8;
+    std::vector<BlockDesc> out;
+    if (row_end <= row_begin || n_cols == 0)
+        return out;
+    const uint64_t BM = (uint64_t)ts.bm, BN = (uint64_t)ts.bn;
+    const uint64_t n_panels = (n_cols + BN - 1) / BN;
+
+    struct Panel {
+        uint64_t j0, first_row, n_tiles;
+    };
+    std::vector<Panel> panels;
+    for (uint64_t pj = 0; pj < n_panels; ++pj) {
+        const uint64_t j0 = pj * BN;
+        const uint64_t jmax = std::min(n_cols, j0 + BN) - 1;  // last real column of the panel
+        // rows i that pair with some column of the panel: square needs i < jmax
+        const uint64_t r_end = square ? std::min(row_end, jmax) : row_end;
+        if (r_end <= row_begin)
+            continue;
+        panels.push_back({j0, row_begin, (r_end - row_begin + BM - 1) / BM});
+    }
+    // longest panels first onto the currently shortest queue
+    std::vector<size_t> order(panels.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return panels[a].n_tiles > panels[b].n_tiles; });
+    std::vector<std::vector<BlockDesc>> queue(kQueues);
+    // a panel much longer than a fair share is split over several queues (few-panel launches)
+    uint64_t total_tiles = 0;
+    for (const Panel &p : panels)
+        total_tiles += p.n_tiles;
+    const uint64_t fair = std::max<uint64_t>(1, (total_tiles + kQueues - 1) / kQueues);
+    for (size_t idx : order) {
+        const Panel &p = panels[idx];
+        uint64_t done = 0;
+        while (done < p.n_tiles) {
+            size_t q = 0;
+            for (size_t k = 1; k < (size_t)kQueues; ++k)
+                if (queue[k].size() < queue[q].size())
+                    q = k;
+            const uint64_t room = fair > queue[q].size() ? fair - queue[q].size() : 1;
+            const uint64_t take = std::min(p.n_tiles - done, std::max<uint64_t>(room, 1));
+            for (uint64_t t = 0; t < take; ++t)
+                queue[q].push_back({(uint32_t)(p.first_row + (done + t) * BM), (uint32_t)p.j0});
+            done += take;
+        }
+    }
+    size_t longest = 0;
+    for (const auto &q : queue)
+        longest = std::max(longest, q.size());
+    out.reserve(longest * kQueues);
+    for (size_t k = 0; k < longest; ++k)
+        for (int q = 0; q < kQueues; ++q)
+            out.push_back(k < queue[q].size() ? queue[q][k] : BlockDesc{0xFFFFFFFFu, 0u});
+    while (!out.empty() && out.back().i0 == 0xFFFFFFFFu)
+        out.pop_back();
+    return out;
+}
+
+}  // namespace dst
+
+// ================================================================================================
+// C ABI: host-only entry points
+// ================================================================================================
+using namespace dst;
+
+extern "C" {
+
+int dst_abi_version(void) { return DST_ABI_VERSION; }
+
+int dst_measure_from_name(const char *name)
+{
+    if (!name)
+        return -1;
+    static const char *names[] = {"n", "n_high", "raw", "jc69", "k80", "tn93"};
+    for (int k = 0; k < 6; ++k)
+        if (std::strcmp(name, names[k]) == 0)
+            return k;
+    return -1;
+}
+
+int dst_tally_width(int measure) { return tally_width(measure); }
+
+const char *dst_status_string(int status)
+{
+    switch (status) {
+    case DST_OK: return "ok";
+    case DST_ERR_ARG: return "bad argument";
+    case DST_ERR_HIP: return "HIP runtime error";
+    case DST_ERR_INVALID_CODE: return "invalid nucleotide code";
+    case DST_ERR_STATE: return "bad state";
+    case DST_ERR_NOMEM: return "out of memory";
+    case DST_ERR_CAPACITY: return "output buffer too small";
+    default: return "unknown status";
+    }
+}
+
+uint64_t dst_square_pairs(uint64_t n) { return n ? n * (n - 1) / 2 : 0; }
+
+uint64_t dst_square_row_start(uint64_t n, uint64_t i) { return square_row_start(n, i); }
+
+int dst_partition_square(uint64_t n, int parts, uint64_t *bounds)
+{
+    if (parts < 1 || !bounds)
+        return DST_ERR_ARG;
+    const uint64_t total = dst_square_pairs(n);
+    bounds[0] = 0;
+    uint64_t row = 0;
+    for (int k = 1; k < parts; ++k) {
+        // first row whose start index reaches k/parts of the pairs (128-bit safe for n < 2^32)
+        const uint64_t target = (uint64_t)(((unsigned __int128)total * (unsigned)k) / (unsigned)parts);
+        uint64_t lo = row, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (square_row_start(n, mid) < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        row = lo;
+        bounds[k] = row;
+    }
+    bounds[parts] = n;
+    return DST_OK;
+}
+
+int dst_partition_rect(uint64_t n_rows, int parts, uint64_t *bounds)
+{
+    if (parts < 1 || !bounds)
+        return DST_ERR_ARG;
+    for (int k = 0; k <= parts; ++k)
+        bounds[k] = (uint64_t)(((unsigned __int128)n_rows * (unsigned)k) / (unsigned)parts);
+    return DST_OK;
+}
+
+size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs)
+{
+    if (out_kind == DST_OUT_TALLY)
+        return (size_t)n_pairs * (size_t)tally_width(measure) * sizeof(uint32_t);
+    return (size_t)n_pairs * 8;
+}
+
+// ---- finalisation: src/measures.rs, same expressions, same order -------------------------------
+static double fin_raw(uint64_t n, uint64_t d) { return (double)n / (double)d; }  // :68
+
+static double fin_jc69(double p) { return -0.75 * std::log(1.0 - (4.0 / 3.0) * p); }  // :76
+
+static double fin_k80(uint64_t count_L, uint64_t ts, uint64_t tv)  // :109-112
+{
+    const double P = (double)ts / (double)count_L;
+    const double Q = (double)tv / (double)count_L;
+    return -0.5 * std::log((1.0 - 2.0 * P - Q) * std::sqrt(1.0 - 2.0 * Q));
+}
+
+static double fin_tn93(const uint32_t *tl, const uint32_t *qc, const uint32_t *tc)  // :118-190
+{
+    const uint64_t qA = qc[0], qT = qc[1], qG = qc[2], qC = qc[3];
+    const uint64_t tA = tc[0], tT = tc[1], tG = tc[2], tC = tc[3];
+    const uint64_t L = qA + qT + qG + qC + tA + tT + tG + tC;
+    const double g_A = ((double)tA + (double)qA) / (double)L;
+    const double g_C = ((double)tC + (double)qC) / (double)L;
+    const double g_G = ((double)tG + (double)qG) / (double)L;
+    const double g_T = ((double)tT + (double)qT) / (double)L;
+    const double g_R = ((double)tA + (double)qA + (double)tG + (double)qG) / (double)L;
+    const double g_Y = ((double)tC + (double)qC + (double)tT + (double)qT) / (double)L;
+    const double k1 = 2.0 * g_A * g_G / g_R;
+    const double k2 = 2.0 * g_T * g_C / g_Y;
+    const double k3 = 2.0 * (g_R * g_Y - g_A * g_G * g_Y / g_R - g_T * g_C * g_R / g_Y);
+    const uint64_t count_L = tl[0], count_d = tl[1], count_P1 = tl[2], count_P2 = tl[3];
+    const double P1 = (double)count_P1 / (double)count_L;
+    const double P2 = (double)count_P2 / (double)count_L;
+    const double Q = (double)(count_d - (count_P1 + count_P2)) / (double)count_L;
+    const double w1 = 1.0 - P1 / k1 - Q / (2.0 * g_R);
+    const double w2 = 1.0 - P2 / k2 - Q / (2.0 * g_Y);
+    const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
+    double d = -k1 * std::log(w1) - k2 * std::log(w2) - k3 * std::log(w3);
+    if (d == 0.0)
+        d = 0.0;
+    return d;
+}
+
+int dst_finalize(int measure, const uint32_t *tallies, const uint32_t *q_counts,
+                 const uint32_t *t_counts, double *as_float, int64_t *as_int)
+{
+    if (!tallies)
+        return DST_ERR_ARG;
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH:
+        if (!as_int)
+            return DST_ERR_ARG;
+        *as_int = (int64_t)tallies[0];
+        return DST_OK;
+    case DST_RAW:
+    case DST_JC69:
+    case DST_K80:
+    case DST_TN93: break;
+    default: return DST_ERR_ARG;
+    }
+    if (!as_float)
+        return DST_ERR_ARG;
+    if (measure == DST_RAW)
+        *as_float = fin_raw(tallies[0], tallies[1]);
+    else if (measure == DST_JC69)
+        *as_float = fin_jc69(fin_raw(tallies[0], tallies[1]));
+    else if (measure == DST_K80)
+        *as_float = fin_k80(tallies[0], tallies[1], tallies[2]);
+    else {
+        if (!q_counts || !t_counts)
+            return DST_ERR_ARG;
+        *as_float = fin_tn93(tallies, q_counts, t_counts);
+    }
+    return DST_OK;
+}
+
+// Rust `{}` for i64 and `{:.12}` for f64 (src/lib.rs:626-633)
+int dst_format_distance(int measure, double as_float, int64_t as_int, char *buf, size_t cap)
+{
+    if (!buf || cap == 0)
+        return -1;
+    if (measure_is_int(measure))
+        return std::snprintf(buf, cap, "%lld", (long long)as_int);
+    if (std::isnan(as_float))
+        return std::snprintf(buf, cap, "NaN");
+    if (std::isinf(as_float))
+        return std::snprintf(buf, cap, as_float < 0 ? "-inf" : "inf");
+    return std::snprintf(buf, cap, "%.12f", as_float);
+}
+
+}  // extern "C"

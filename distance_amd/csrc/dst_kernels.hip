@@ -1,0 +1,632 @@
+// dst_kernels.hip — hand-written gfx950 (MI355X, CDNA4) kernels of the all-pairs distance path.
+//
+//   pack_kernel      Paradis bytes (src/encoding.rs:4-41)  ->  8 bit-planes, validates codes
+//   counts_kernel    per-record {A,T,G,C} counts            (src/fastaio.rs:53-66)
+//   pair_kernel<M>   site tallies of every pair of a tile   (src/measures.rs:14-23, 56-66,
+//                                                            85-107, 156-175)
+//   finalize_kernel  tallies -> f64 distance, reference operation order
+//                                                           (src/measures.rs:68, 76, 109-112,
+//                                                            118-190)
+//
+// Design (DESIGN.md has the numbers): integer / bitwise work, no MFMA.  One pair costs 5..10
+// VALU ops per 32 sites.  A block owns BM "row" records x 256*TN "column" records.  Each lane
+// owns TN column records and keeps their plane words in VGPRs; the row records are wave-uniform,
+// so their plane words arrive through SCALAR loads (s_load_dwordx4.. via the scalar cache) and
+// feed the VALU as SGPR operands: no LDS traffic, no barriers, accumulators live in VGPRs for the
+// whole sweep over L, and every VALU slot does site work (v_and_b32 / v_and_or_b32 /
+// v_bcnt_u32_b32).  Tiles of one column panel are dealt to workgroups that share an XCD so the
+// panel streams from HBM once per XCD and is then served by that XCD's L2.
+#include "dst_internal.h"
+
+namespace dst {
+
+// =============================================================================================
+// pack: bytes -> planes
+// =============================================================================================
+namespace {
+
+constexpr uint32_t H8 = 0x80808080u;
+
+// bit 7 of each of the 4 bytes of m -> 4 low bits (byte 0 -> bit 0).  The partial products of
+// 0x00204081 land on distinct bit positions, so no carry reaches bits 28..31.
+__device__ __forceinline__ uint32_t gather4(uint32_t m) { return (m * 0x00204081u) >> 28; }
+
+struct Planes4 {  // 4 sites' worth of every plane, in the low 4 bits
+    uint32_t p[PL_COUNT];
+    uint32_t bad;  // non-zero: one of the 4 bytes is not a Paradis code
+};
+
+__device__ __forceinline__ Planes4 split4(uint32_t x)
+{
+    const uint32_t A = x & H8, G = (x << 1) & H8, C = (x << 2) & H8, T = (x << 3) & H8;
+    const uint32_t K = (x << 4) & H8;
+    const uint32_t pur = A | G, pyr = C | T;
+    const uint32_t X1 = pyr & ~pur;          // {C,T,Y}
+    const uint32_t CL = X1 | (pur & ~pyr);   // plus {A,G,R}
+    const uint32_t X0 = K & (G | T);
+    // validity: one base bit -> low nibble 8; all four -> low nibble 0 (N), 4 (-) or 2 (?);
+    // two or three -> low nibble 0; none -> invalid.
+    const uint32_t onehot = (A ^ G ^ C ^ T) & ~((A & G) | (C & T));
+    const uint32_t all4 = A & G & C & T;
+    const uint32_t none = H8 & ~(A | G | C | T);
+    const uint32_t low = x & 0x0F0F0F0Fu;
+    const uint32_t all4m = (all4 >> 7) * 6u;
+    Planes4 r;
+    r.bad = ((low ^ (onehot >> 4)) & ~all4m) | none | (((low & all4m) + 0x02020202u) & 0x08080808u);
+    r.p[PL_A] = gather4(A);
+    r.p[PL_G] = gather4(G);
+    r.p[PL_C] = gather4(C);
+    r.p[PL_T] = gather4(T);
+    r.p[PL_K] = gather4(K);
+    r.p[PL_X1] = gather4(X1);
+    r.p[PL_X0] = gather4(X0);
+    r.p[PL_CL] = gather4(CL);
+    return r;
+}
+
+// One thread = one (record, 128-site chunk).  Lanes run along records, so the eight 16-byte
+// plane stores of a wave are 1 KiB contiguous each; every lane reads its own 128-byte line.
+// Sites >= len and records >= n are filled with N (0xF0): N contributes nothing to any tally.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ codes,
+                                                   size_t row_stride, uint32_t n, uint32_t len,
+                                                   uint32_t nchunks, uint32_t npad,
+                                                   uint4 *__restrict__ planes,
+                                                   unsigned long long *__restrict__ first_bad,
+                                                   int aligned16)
+{
+    const uint32_t s = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (s >= npad)
+        return;
+    uint32_t out[PL_COUNT][4];
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            out[p][w] = (p <= PL_T) ? 0xFFFFFFFFu : 0u;  // all N
+
+    if (s < n) {
+        const uint32_t site0 = c * kChunkSites;
+        const uint8_t *row = codes + (size_t)s * row_stride + site0;
+        const bool fast = aligned16 && site0 + kChunkSites <= len;
+        uint32_t bad_at = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t x[8];
+            if (fast) {
+                const uint4 lo = reinterpret_cast<const uint4 *>(row)[2 * w];
+                const uint4 hi = reinterpret_cast<const uint4 *>(row)[2 * w + 1];
+                x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+                x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t off = 32 * w + 4 * g + b;
+                        const uint32_t byte = site0 + off < len ? row[off] : 0xF0u;
+                        v |= byte << (8 * b);
+                    }
+                    x[g] = v;
+                }
+            }
+            uint32_t acc[PL_COUNT];
+#pragma unroll
+            for (int p = 0; p < PL_COUNT; ++p)
+                acc[p] = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const Planes4 r = split4(x[g]);
+#pragma unroll
+                for (int p = 0; p < PL_COUNT; ++p)
+                    acc[p] |= r.p[p] << (4 * g);
+                if (r.bad && bad_at == 0xFFFFFFFFu) {
+                    // first offending byte of this group: bad has a bit in its byte lane
+                    const uint32_t lane = (__builtin_ctz(r.bad)) >> 3;
+                    bad_at = 32 * w + 4 * g + lane;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PL_COUNT; ++p)
+                out[p][w] = acc[p];
+        }
+        if (bad_at != 0xFFFFFFFFu)
+            atomicMin(first_bad, (unsigned long long)s * len + site0 + bad_at);
+    }
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+        planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+}
+
+// {A,T,G,C} counts by code (src/fastaio.rs:53-66): a known base is K & its own bit-plane.
+__global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ planes,
+                                                     uint32_t nchunks, uint32_t npad,
+                                                     uint32_t *__restrict__ counts)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= npad)
+        return;
+    uint32_t a = 0, t = 0, g = 0, cc = 0;
+    const size_t ps = (size_t)nchunks * npad;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const size_t at = (size_t)c * npad + s;
+        const uint4 K = planes[PL_K * ps + at];
+        const uint4 A = planes[PL_A * ps + at], G = planes[PL_G * ps + at];
+        const uint4 C = planes[PL_C * ps + at], T = planes[PL_T * ps + at];
+        a += __builtin_popcount(K.x & A.x) + __builtin_popcount(K.y & A.y) +
+             __builtin_popcount(K.z & A.z) + __builtin_popcount(K.w & A.w);
+        t += __builtin_popcount(K.x & T.x) + __builtin_popcount(K.y & T.y) +
+             __builtin_popcount(K.z & T.z) + __builtin_popcount(K.w & T.w);
+        g += __builtin_popcount(K.x & G.x) + __builtin_popcount(K.y & G.y) +
+             __builtin_popcount(K.z & G.z) + __builtin_popcount(K.w & G.w);
+        cc += __builtin_popcount(K.x & C.x) + __builtin_popcount(K.y & C.y) +
+              __builtin_popcount(K.z & C.z) + __builtin_popcount(K.w & C.w);
+    }
+    reinterpret_cast<uint4 *>(counts)[s] = make_uint4(a, t, g, cc);
+}
+
+// =============================================================================================
+// measures: per-32-site step on plane words + conversion of the raw popcounts to the
+// reference's tallies.  q = row record (SGPR operands), t = column record (VGPR operands).
+// =============================================================================================
+// The inner ops are pinned.  Left to itself hipcc rebalances the OR-of-ANDs into 5 ops instead
+// of 4 and splits chained popcount-accumulates into v_bcnt(x,0) + v_add3 (1.5 issue slots per
+// tally instead of 1).  Boolean steps use the gfx950 v_bitop3_b32 builtin (any function of three
+// inputs, TT = f(0xF0, 0xCC, 0xAA)); the accumulate is a one-instruction asm.  Only the bcnt is
+// asm: hipcc pads back-to-back dependent asm statements with s_nop (dst-forwarding hazard it
+// cannot rule out), and with ordinary VALU in between the scheduler never needs to.
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c)  // (a & b) | c
+{
+    return bitop3<((0xF0 & 0xCC) | 0xAA)>(a, b, c);
+}
+__device__ __forceinline__ void bcnt_acc(uint32_t &acc, uint32_t x)  // acc += popcount(x)
+{
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+constexpr int TT_AND3 = 0xF0 & 0xCC & 0xAA;          // a & b & c
+constexpr int TT_A_AND_B_EQ_C = 0xF0 & ~(0xCC ^ 0xAA) & 0xFF;  // a & ~(b ^ c)
+constexpr int TT_A_AND_B_NE_C = 0xF0 & (0xCC ^ 0xAA);          // a & (b ^ c)
+constexpr int TT_A_AND_B_ANDN_C = 0xF0 & 0xCC & 0x55;          // a & b & ~c
+
+// share = the two base sets intersect  <=>  NOT "certainly different" ((q & t) < 16 on bytes)
+__device__ __forceinline__ uint32_t share_bits(const uint32_t *q, const uint32_t *t)
+{
+    return and_or(q[3], t[3], and_or(q[2], t[2], and_or(q[1], t[1], q[0] & t[0])));
+}
+
+struct MNHigh {  // src/measures.rs:14-23  d = #{(q&t) < 16}                       5 ops / 32 sites
+    static constexpr int NP = 4, NC = 1, NT = 1, P0 = PL_A;  // planes A,G,C,T
+    static __device__ __forceinline__ void step(uint32_t *a, const uint32_t *q, const uint32_t *t)
+    {
+        bcnt_acc(a[0], share_bits(q, t));
+    }
+    static __device__ __forceinline__ void tallies(const uint32_t *a, uint32_t total, uint32_t *o)
+    {
+        o[0] = total - a[0];
+    }
+};
+
+struct MRaw {  // src/measures.rs:56-66  same: known & equal; else different      7 ops / 32 sites
+    static constexpr int NP = 5, NC = 2, NT = 2, P0 = PL_A;  // planes A,G,C,T,K
+    static __device__ __forceinline__ void step(uint32_t *a, const uint32_t *q, const uint32_t *t)
+    {
+        const uint32_t share = share_bits(q, t);
+        bcnt_acc(a[0], share);
+        bcnt_acc(a[1], bitop3<TT_AND3>(share, q[4], t[4]));  // both known and intersecting = equal
+    }
+    static __device__ __forceinline__ void tallies(const uint32_t *a, uint32_t total, uint32_t *o)
+    {
+        const uint32_t n = total - a[0];
+        o[0] = n;         // n
+        o[1] = n + a[1];  // d
+    }
+};
+
+struct MK80 {  // src/measures.rs:85-107                                          7 ops / 32 sites
+    static constexpr int NP = 4, NC = 3, NT = 3, P0 = PL_K;  // planes K,X1,X0,CL
+    static __device__ __forceinline__ void step(uint32_t *a, const uint32_t *q, const uint32_t *t)
+    {
+        const uint32_t e1 = q[1] ^ t[1];                                 // classes differ
+        const uint32_t sc = bitop3<TT_A_AND_B_ANDN_C>(q[0], t[0], e1);   // both known, same class
+        const uint32_t ts = bitop3<TT_A_AND_B_NE_C>(sc, q[2], t[2]);     // A<->G or C<->T
+        const uint32_t tv = bitop3<TT_AND3>(q[3], t[3], e1);             // purine vs pyrimidine class
+        bcnt_acc(a[0], sc);
+        bcnt_acc(a[1], ts);
+        bcnt_acc(a[2], tv);
+    }
+    static __device__ __forceinline__ void tallies(const uint32_t *a, uint32_t, uint32_t *o)
+    {
+        o[0] = a[0] + a[2];  // count_L = same + ts + tv   (sc = same + ts)
+        o[1] = a[1];         // ts
+        o[2] = a[2];         // tv
+    }
+};
+
+struct MTN93 {  // src/measures.rs:156-175                                        8 ops / 32 sites
+    static constexpr int NP = 3, NC = 4, NT = 4, P0 = PL_K;  // planes K,X1,X0
+    static __device__ __forceinline__ void step(uint32_t *a, const uint32_t *q, const uint32_t *t)
+    {
+        const uint32_t bk = q[0] & t[0];                                 // both known
+        const uint32_t sc = bitop3<TT_A_AND_B_EQ_C>(bk, q[1], t[1]);     // same class
+        const uint32_t ts = bitop3<TT_A_AND_B_NE_C>(sc, q[2], t[2]);     // transition
+        const uint32_t p2 = ts & q[1];                                   // ... between pyrimidines
+        bcnt_acc(a[0], bk);
+        bcnt_acc(a[1], sc);
+        bcnt_acc(a[2], ts);
+        bcnt_acc(a[3], p2);
+    }
+    static __device__ __forceinline__ void tallies(const uint32_t *a, uint32_t, uint32_t *o)
+    {
+        o[0] = a[0];                  // count_L  (same + different, both known)
+        o[1] = a[0] - (a[1] - a[2]);  // count_d  = L - same
+        o[2] = a[2] - a[3];           // count_P1 (A<->G)
+        o[3] = a[3];                  // count_P2 (C<->T)
+    }
+};
+
+__device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
+{
+    return i * (2 * n - i - 1) / 2;
+}
+
+// =============================================================================================
+// pair kernel
+// =============================================================================================
+// One block = BM row records x 256*TN column records, 256 threads (4 waves), 2 blocks per CU.
+// Per 128-site chunk:
+//   columns: each lane loads its TN records' NP plane words straight from HBM/L2 into VGPRs
+//            (16 B per lane, 1 KiB contiguous per wave-instruction) and keeps them for all BM rows;
+//   rows:    the BM x NP uint4 row tile (<= 5 KiB) is staged through LDS, double-buffered, one
+//            barrier per chunk; every lane reads the same 16 bytes (broadcast ds_read_b128), so
+//            LDS time is 4 cycles per plane per row per wave against 64*TN VALU cycles;
+//   tallies: BM*TN*NC accumulators live in VGPRs for the whole sweep over L.
+template <class M, int BM, int TN, bool INT_OUT>
+__global__ __launch_bounds__(256, 2) void pair_kernel(
+    const uint4 *__restrict__ qpl, const uint4 *__restrict__ tpl,
+    const BlockDesc *__restrict__ blocks, uint32_t *__restrict__ tallies,
+    int64_t *__restrict__ int_out, uint32_t nchunks, uint32_t q_npad, uint32_t t_npad,
+    uint32_t n_cols, uint32_t row_begin, uint32_t row_end, uint64_t out_base, int square)
+{
+    constexpr int NP = M::NP, NC = M::NC;
+    constexpr int QV = NP * BM;               // uint4 per staged row tile
+    constexpr int QL = (QV + 255) / 256;      // staging loads per thread
+    __shared__ uint4 qs[2][NP][BM];
+
+    const uint32_t i0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].i0);
+    const uint32_t j0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].j0);
+    if (i0 == 0xFFFFFFFFu)
+        return;
+
+    uint32_t acc[BM][TN][NC];
+#pragma unroll
+    for (int r = 0; r < BM; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                acc[r][tn][k] = 0;
+
+    const size_t q_ps = (size_t)nchunks * q_npad;  // plane stride, in uint4
+    const size_t t_ps = (size_t)nchunks * t_npad;
+    // staging element(s) of this thread: (plane sp, row sr) of the row tile
+    const uint4 *qsrc[QL];
+    uint4 *qdst0[QL];
+#pragma unroll
+    for (int k = 0; k < QL; ++k) {
+        const int e = (int)threadIdx.x + 256 * k;
+        const int sp = e / BM, sr = e % BM;
+        qsrc[k] = qpl + (size_t)(M::P0 + (e < QV ? sp : 0)) * q_ps + i0 + sr;
+        qdst0[k] = &qs[0][e < QV ? sp : 0][sr];
+    }
+    const uint4 *tchunk = tpl + (size_t)M::P0 * t_ps + j0 + threadIdx.x;  // += t_npad per chunk
+
+    // prologue: chunk 0 of the row tile
+#pragma unroll
+    for (int k = 0; k < QL; ++k)
+        if ((int)threadIdx.x + 256 * k < QV)
+            *qdst0[k] = qsrc[k][0];
+    __syncthreads();
+
+#pragma unroll 1
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t buf = c & 1u;
+        const bool more = c + 1 < nchunks;
+        uint4 qnext[QL];
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < QL; ++k)
+                if ((int)threadIdx.x + 256 * k < QV)
+                    qnext[k] = qsrc[k][(size_t)(c + 1) * q_npad];
+        }
+        uint4 tv[NP][TN];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                tv[p][tn] = tchunk[(size_t)p * t_ps + 256 * tn];
+        tchunk += t_npad;
+
+#pragma unroll
+        for (int r = 0; r < BM; ++r) {
+            uint4 qv[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                qv[p] = qs[buf][p][r];  // same address in every lane: broadcast read
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                uint32_t q[NP], t[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { q[p] = qv[p].x; t[p] = tv[p][tn].x; }
+                M::step(acc[r][tn], q, t);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { q[p] = qv[p].y; t[p] = tv[p][tn].y; }
+                M::step(acc[r][tn], q, t);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { q[p] = qv[p].z; t[p] = tv[p][tn].z; }
+                M::step(acc[r][tn], q, t);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { q[p] = qv[p].w; t[p] = tv[p][tn].w; }
+                M::step(acc[r][tn], q, t);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < QL; ++k)
+                if ((int)threadIdx.x + 256 * k < QV)
+                    qdst0[k][(buf ^ 1u) * (NP * BM)] = qnext[k];
+        }
+        __syncthreads();
+    }
+
+    const uint32_t total = nchunks * kChunkSites;  // padded sites are N on both sides: "share"
+#pragma unroll
+    for (int r = 0; r < BM; ++r) {
+        const uint32_t i = i0 + r;
+        if (i >= row_end)
+            break;
+        const uint64_t row_at = square ? (tri_row_start(n_cols, i) - out_base) - (uint64_t)(i + 1)
+                                       : (uint64_t)(i - row_begin) * n_cols;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const uint32_t j = j0 + 256 * tn + threadIdx.x;
+            if (j < n_cols && (!square || j > i)) {
+                const uint64_t at = row_at + j;
+                uint32_t o[M::NT];
+                M::tallies(acc[r][tn], total, o);
+                if constexpr (INT_OUT) {
+                    int_out[at] = (int64_t)o[0];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < M::NT; ++k)
+                        tallies[at * M::NT + k] = o[k];
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// finalize: tallies -> f64, the reference's operation order.  contract(off): rustc never fuses.
+// =============================================================================================
+// (the build passes -ffp-contract=off for the whole file)
+__device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
+{
+    return (double)n / (double)d;
+}
+
+__device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d)  // src/measures.rs:72-77
+{
+    const double p = fin_raw(n, d);
+    return -0.75 * log(1.0 - (4.0 / 3.0) * p);
+}
+
+__device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv)  // :109-112
+{
+    const double P = (double)ts / (double)count_L;
+    const double Q = (double)tv / (double)count_L;
+    return -0.5 * log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
+}
+
+// counts = {A, T, G, C}; sums keep the reference's operand order (target first), :118-190
+__device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
+                                           uint32_t count_P2, uint4 qc, uint4 tc)
+{
+    const uint64_t L = (uint64_t)qc.x + qc.y + qc.z + qc.w + tc.x + tc.y + tc.z + tc.w;
+    const double g_A = ((double)tc.x + (double)qc.x) / (double)L;
+    const double g_C = ((double)tc.w + (double)qc.w) / (double)L;
+    const double g_G = ((double)tc.z + (double)qc.z) / (double)L;
+    const double g_T = ((double)tc.y + (double)qc.y) / (double)L;
+    const double g_R = ((double)tc.x + (double)qc.x + (double)tc.z + (double)qc.z) / (double)L;
+    const double g_Y = ((double)tc.w + (double)qc.w + (double)tc.y + (double)qc.y) / (double)L;
+    const double k1 = 2.0 * g_A * g_G / g_R;
+    const double k2 = 2.0 * g_T * g_C / g_Y;
+    const double k3 = 2.0 * (g_R * g_Y - g_A * g_G * g_Y / g_R - g_T * g_C * g_R / g_Y);
+    const double P1 = (double)count_P1 / (double)count_L;
+    const double P2 = (double)count_P2 / (double)count_L;
+    const double Q = (double)(count_d - (count_P1 + count_P2)) / (double)count_L;
+    const double w1 = 1.0 - P1 / k1 - Q / (2.0 * g_R);
+    const double w2 = 1.0 - P2 / k2 - Q / (2.0 * g_Y);
+    const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
+    double d = -k1 * log(w1) - k2 * log(w2) - k3 * log(w3);
+    if (d == 0.0)
+        d = 0.0;
+    return d;
+}
+
+// one block per row of the launch; threads stride along the row's pairs (coalesced)
+template <int MEASURE>
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ tallies,
+                                                       const uint32_t *__restrict__ q_counts,
+                                                       const uint32_t *__restrict__ t_counts,
+                                                       double *__restrict__ out, uint32_t n_cols,
+                                                       uint32_t row_begin, uint64_t out_base,
+                                                       int square)
+{
+    const uint32_t i = row_begin + blockIdx.x;
+    const uint32_t jstart = square ? i + 1 : 0;
+    if (jstart >= n_cols)
+        return;
+    const uint64_t base = square ? tri_row_start(n_cols, i) - out_base
+                                 : (uint64_t)(i - row_begin) * n_cols;
+    uint4 qc = make_uint4(0, 0, 0, 0);
+    if constexpr (MEASURE == DST_TN93)
+        qc = reinterpret_cast<const uint4 *>(q_counts)[i];
+    for (uint32_t k = threadIdx.x; k < n_cols - jstart; k += blockDim.x) {
+        const uint64_t at = base + k;
+        double d;
+        if constexpr (MEASURE == DST_RAW || MEASURE == DST_JC69) {
+            const uint2 v = reinterpret_cast<const uint2 *>(tallies)[at];
+            d = MEASURE == DST_RAW ? fin_raw(v.x, v.y) : fin_jc69(v.x, v.y);
+        } else if constexpr (MEASURE == DST_K80) {
+            const uint32_t *v = tallies + at * 3;
+            d = fin_k80(v[0], v[1], v[2]);
+        } else {
+            const uint4 v = reinterpret_cast<const uint4 *>(tallies)[at];
+            const uint4 tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
+            d = fin_tn93(v.x, v.y, v.z, v.w, qc, tc);
+        }
+        out[at] = d;
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
+                       unsigned long long *d_first_bad, hipStream_t stream)
+{
+    const int aligned16 = (reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0);
+    dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
+                       (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
+                       d_first_bad, aligned16);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream)
+{
+    hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((set.npad + 255) / 256)), dim3(256), 0, stream,
+                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, set.counts);
+    return hipGetLastError();
+}
+
+namespace {
+
+struct Variant {
+    int bm, tn;
+};
+// tile variants per measure family; [0] is the default.  DESIGN.md "tile variants".
+constexpr Variant kVarNHigh[] = {{32, 4}, {64, 2}, {32, 2}, {16, 4}};
+constexpr Variant kVarRaw[] = {{32, 2}, {16, 4}, {16, 2}, {24, 2}};
+constexpr Variant kVarK80[] = {{16, 2}, {8, 2}, {12, 2}};
+constexpr Variant kVarTN93[] = {{16, 2}, {8, 4}, {12, 2}};
+
+template <class M, int BM, int TN, bool INT_OUT>
+hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
+{
+    hipLaunchKernelGGL((pair_kernel<M, BM, TN, INT_OUT>), dim3(pl.nblocks), dim3(256), 0, stream,
+                       pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_tallies, pl.d_int_out,
+                       (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad, (uint32_t)pl.cols->npad,
+                       (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, (uint32_t)pl.row_end,
+                       pl.out_base, pl.square ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int variant_count(int measure)
+{
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH: return (int)(sizeof kVarNHigh / sizeof kVarNHigh[0]);
+    case DST_RAW:
+    case DST_JC69: return (int)(sizeof kVarRaw / sizeof kVarRaw[0]);
+    case DST_K80: return (int)(sizeof kVarK80 / sizeof kVarK80[0]);
+    case DST_TN93: return (int)(sizeof kVarTN93 / sizeof kVarTN93[0]);
+    default: return 0;
+    }
+}
+
+TileShape tile_shape(int measure, int variant)
+{
+    const int nv = variant_count(measure);
+    if (variant < 0 || variant >= nv)
+        variant = 0;
+    Variant v{32, 1};
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH: v = kVarNHigh[variant]; break;
+    case DST_RAW:
+    case DST_JC69: v = kVarRaw[variant]; break;
+    case DST_K80: v = kVarK80[variant]; break;
+    case DST_TN93: v = kVarTN93[variant]; break;
+    default: break;
+    }
+    return TileShape{v.bm, 256 * v.tn};
+}
+
+#define DST_CASE(M, BM_, TN_, IO)                                   \
+    if (ts.bm == BM_ && ts.bn == 256 * TN_)                         \
+        return launch_one<M, BM_, TN_, IO>(pl, stream);
+
+hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream)
+{
+    const TileShape ts = tile_shape(measure, variant);
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH:
+        if (pl.d_int_out) {
+            DST_CASE(MNHigh, 32, 4, true) DST_CASE(MNHigh, 64, 2, true)
+            DST_CASE(MNHigh, 32, 2, true) DST_CASE(MNHigh, 16, 4, true)
+        } else {
+            DST_CASE(MNHigh, 32, 4, false) DST_CASE(MNHigh, 64, 2, false)
+            DST_CASE(MNHigh, 32, 2, false) DST_CASE(MNHigh, 16, 4, false)
+        }
+        break;
+    case DST_RAW:
+    case DST_JC69:
+        DST_CASE(MRaw, 32, 2, false) DST_CASE(MRaw, 16, 4, false)
+        DST_CASE(MRaw, 16, 2, false) DST_CASE(MRaw, 24, 2, false)
+        break;
+    case DST_K80:
+        DST_CASE(MK80, 16, 2, false) DST_CASE(MK80, 8, 2, false) DST_CASE(MK80, 12, 2, false)
+        break;
+    case DST_TN93:
+        DST_CASE(MTN93, 16, 2, false) DST_CASE(MTN93, 8, 4, false) DST_CASE(MTN93, 12, 2, false)
+        break;
+    default: break;
+    }
+    return hipErrorInvalidValue;
+}
+#undef DST_CASE
+
+hipError_t launch_finalize(int measure, const PairLaunch &pl, double *d_out, hipStream_t stream)
+{
+    const unsigned rows = (unsigned)(pl.row_end - pl.row_begin);
+    if (rows == 0)
+        return hipSuccess;
+    const uint32_t *qc = pl.rows->counts, *tc = pl.cols->counts;
+#define DST_FIN(MEAS)                                                                            \
+    hipLaunchKernelGGL((finalize_kernel<MEAS>), dim3(rows), dim3(256), 0, stream, pl.d_tallies,  \
+                       qc, tc, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, pl.out_base, \
+                       pl.square ? 1 : 0)
+    switch (measure) {
+    case DST_RAW: DST_FIN(DST_RAW); break;
+    case DST_JC69: DST_FIN(DST_JC69); break;
+    case DST_K80: DST_FIN(DST_K80); break;
+    case DST_TN93: DST_FIN(DST_TN93); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DST_FIN
+    return hipGetLastError();
+}
+
+}  // namespace dst

@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's run() boundary over the C ABI.
+
+`Engine` owns one dst_ctx (one GPU).  Naming follows the reference: `upload` replaces
+Setup.loaded_fastas (src/lib.rs:133-144), `run_square`/`run_rect` replace load() with one/two
+files (src/lib.rs:367-474), `run_stream_batch` replaces stream()'s inner loops
+(src/lib.rs:322-333).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import DistanceError, load
+
+MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
+INT_MEASURES = ("n", "n_high")
+FLOAT_MEASURES = ("raw", "jc69", "k80", "tn93")
+OUT_DISTANCE, OUT_TALLY = 0, 1
+
+
+def _measure_id(measure) -> int:
+    if isinstance(measure, str):
+        m = load().dst_measure_from_name(measure.encode())
+        if m < 0:
+            raise ValueError(f"Unknown distance measure {measure!r}")  # src/lib.rs:486
+        return m
+    return int(measure)
+
+
+def tally_width(measure) -> int:
+    return load().dst_tally_width(_measure_id(measure))
+
+
+def square_pairs(n: int) -> int:
+    return int(load().dst_square_pairs(n))
+
+
+def square_row_start(n: int, i: int) -> int:
+    return int(load().dst_square_row_start(n, i))
+
+
+def partition_square(n: int, parts: int) -> list[int]:
+    """Row bounds of `parts` contiguous row ranges with near-equal pair counts (multi-GPU cut)."""
+    b = (C.c_uint64 * (parts + 1))()
+    rc = load().dst_partition_square(n, parts, b)
+    if rc:
+        raise DistanceError(rc, "dst_partition_square")
+    return [int(x) for x in b]
+
+
+def partition_rect(n_rows: int, parts: int) -> list[int]:
+    b = (C.c_uint64 * (parts + 1))()
+    rc = load().dst_partition_rect(n_rows, parts, b)
+    if rc:
+        raise DistanceError(rc, "dst_partition_rect")
+    return [int(x) for x in b]
+
+
+def plan_tiles(square: bool, row_begin: int, row_end: int, n_cols: int, measure, variant: int = 0):
+    """Tile schedule of one launch: (tiles[(i0, j0)...] with idle fillers dropped, tile_rows, tile_cols)."""
+    m = _measure_id(measure)
+    count, bm, bn = C.c_size_t(), C.c_int(), C.c_int()
+    lib = load()
+    rc = lib.dst_plan_tiles(int(square), row_begin, row_end, n_cols, m, variant, None, 0, C.byref(count),
+                            C.byref(bm), C.byref(bn))
+    if rc:
+        raise DistanceError(rc, "dst_plan_tiles")
+    ij = np.zeros((max(count.value, 1), 2), np.uint32)
+    rc = lib.dst_plan_tiles(int(square), row_begin, row_end, n_cols, m, variant, ij.ctypes.data,
+                            count.value, C.byref(count), None, None)
+    if rc:
+        raise DistanceError(rc, "dst_plan_tiles")
+    ij = ij[:count.value]
+    return ij, bm.value, bn.value
+
+
+def finalize(measure, tallies, q_counts=None, t_counts=None):
+    """Host finalisation in the reference's f64 operation order (dst_finalize)."""
+    m = _measure_id(measure)
+    t = np.ascontiguousarray(tallies, np.uint32)
+    qc = None if q_counts is None else np.ascontiguousarray(q_counts, np.uint32)
+    tc = None if t_counts is None else np.ascontiguousarray(t_counts, np.uint32)
+    f, i = C.c_double(), C.c_int64()
+    rc = load().dst_finalize(m, t.ctypes.data, None if qc is None else qc.ctypes.data,
+                             None if tc is None else tc.ctypes.data, C.byref(f), C.byref(i))
+    if rc:
+        raise DistanceError(rc, "dst_finalize")
+    return int(i.value) if m in (0, 1) else float(f.value)
+
+
+def format_distance(measure, value) -> str:
+    m = _measure_id(measure)
+    buf = C.create_string_buffer(64)
+    if m in (0, 1):
+        load().dst_format_distance(m, 0.0, int(value), buf, 64)
+    else:
+        load().dst_format_distance(m, float(value), 0, buf, 64)
+    return buf.value.decode()
+
+
+class Engine:
+    """One GPU's context.  `device` is the HIP device ordinal."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.dst_create(device, C.byref(h))
+        if rc:
+            raise DistanceError(rc, self._lib.dst_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dst_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc:
+            raise DistanceError(rc, self._lib.dst_last_error(self._h).decode())
+
+    # ---- knobs -----------------------------------------------------------------------------
+    def set_variant(self, variant: int):
+        self._check(self._lib.dst_set_variant(self._h, variant))
+
+    def set_scratch_limit(self, nbytes: int):
+        self._check(self._lib.dst_set_scratch_limit(self._h, nbytes))
+
+    # ---- input -----------------------------------------------------------------------------
+    def upload(self, slot: int, codes: np.ndarray, base_counts: np.ndarray | None = None):
+        """codes: (n, L) uint8 Paradis codes (any row stride); base_counts: (n, 4) {A,T,G,C}."""
+        codes = np.asarray(codes)
+        if codes.dtype != np.uint8 or codes.ndim != 2:
+            raise ValueError("codes must be a 2-D uint8 array")
+        if codes.shape[1] and codes.strides[1] != 1:
+            codes = np.ascontiguousarray(codes)
+        stride = codes.strides[0] if codes.shape[0] > 1 else max(codes.shape[1], 1)
+        bc = None
+        if base_counts is not None:
+            bc = np.ascontiguousarray(base_counts, np.uint32)
+            if bc.shape != (codes.shape[0], 4):
+                raise ValueError("base_counts must be (n, 4)")
+        self._check(self._lib.dst_upload(self._h, slot, codes.ctypes.data, codes.shape[0], codes.shape[1],
+                                         stride, None if bc is None else bc.ctypes.data))
+
+    def upload_device(self, slot: int, d_ptr: int, n: int, length: int, row_stride: int,
+                      d_counts_ptr: int | None = None, stream: int | None = None):
+        self._check(self._lib.dst_upload_device(self._h, slot, d_ptr, n, length, row_stride, d_counts_ptr,
+                                                stream))
+
+    def set_info(self, slot: int) -> tuple[int, int]:
+        n, length = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.dst_set_info(self._h, slot, C.byref(n), C.byref(length)))
+        return int(n.value), int(length.value)
+
+    def base_counts(self, slot: int) -> np.ndarray:
+        n, _ = self.set_info(slot)
+        out = np.zeros((n, 4), np.uint32)
+        self._check(self._lib.dst_get_base_counts(self._h, slot, out.ctypes.data))
+        return out
+
+    # ---- runs into host memory ---------------------------------------------------------------
+    def _alloc(self, m: int, out_kind: int, pairs: int) -> np.ndarray:
+        if out_kind == OUT_TALLY:
+            return np.zeros((pairs, self._lib.dst_tally_width(m)), np.uint32)
+        return np.zeros(pairs, np.int64 if m in (0, 1) else np.float64)
+
+    def run_square(self, measure, row_begin: int = 0, row_end: int | None = None,
+                   tallies: bool = False) -> np.ndarray:
+        """Distances (or tallies) of pairs (i, j), row_begin <= i < row_end, j > i, canonical order."""
+        m = _measure_id(measure)
+        n, _ = self.set_info(0)
+        row_end = n if row_end is None else row_end
+        pairs = square_row_start(n, min(row_end, n)) - square_row_start(n, min(row_begin, n)) \
+            if row_end > row_begin else 0
+        kind = OUT_TALLY if tallies else OUT_DISTANCE
+        out = self._alloc(m, kind, pairs)
+        self._check(self._lib.dst_run_square_host(self._h, m, row_begin, row_end, kind, out.ctypes.data,
+                                                  out.nbytes))
+        return out
+
+    def run_rect(self, measure, row_slot: int = 0, col_slot: int = 1, row_begin: int = 0,
+                 row_end: int | None = None, tallies: bool = False) -> np.ndarray:
+        m = _measure_id(measure)
+        n_rows, _ = self.set_info(row_slot)
+        n_cols, _ = self.set_info(col_slot)
+        row_end = n_rows if row_end is None else row_end
+        kind = OUT_TALLY if tallies else OUT_DISTANCE
+        out = self._alloc(m, kind, max(row_end - row_begin, 0) * n_cols)
+        self._check(self._lib.dst_run_rect_host(self._h, m, row_slot, col_slot, row_begin, row_end, kind,
+                                                out.ctypes.data, out.nbytes))
+        return out.reshape((max(row_end - row_begin, 0), n_cols) + out.shape[1:])
+
+    def run_stream_batch(self, measure, batch_codes: np.ndarray, batch_counts=None,
+                         tallies: bool = False) -> np.ndarray:
+        """One streamed batch against the loaded set in slot 0 (src/lib.rs:322-333): returns
+        [streamed record][loaded record], i.e. the reference's streamed-major output order."""
+        self.upload(1, batch_codes, batch_counts)
+        return self.run_rect(measure, row_slot=1, col_slot=0, tallies=tallies)
+
+    # ---- runs into device memory (bench / multi-GPU) ------------------------------------------
+    def run_square_device(self, measure, row_begin: int, row_end: int, d_out: int, capacity: int,
+                          tallies: bool = False, stream: int | None = None):
+        m = _measure_id(measure)
+        self._check(self._lib.dst_run_square(self._h, m, row_begin, row_end,
+                                             OUT_TALLY if tallies else OUT_DISTANCE, d_out, capacity, stream))
+
+    def run_rect_device(self, measure, row_slot: int, col_slot: int, row_begin: int, row_end: int,
+                        d_out: int, capacity: int, tallies: bool = False, stream: int | None = None):
+        m = _measure_id(measure)
+        self._check(self._lib.dst_run_rect(self._h, m, row_slot, col_slot, row_begin, row_end,
+                                           OUT_TALLY if tallies else OUT_DISTANCE, d_out, capacity, stream))
+
+    def last_kernel_ms(self) -> dict:
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        self._check(self._lib.dst_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pair_ms": a.value, "finalize_ms": b.value, "pack_ms": c.value}
+
+    def out_bytes(self, measure, pairs: int, tallies: bool = False) -> int:
+        return int(self._lib.dst_out_bytes(_measure_id(measure), OUT_TALLY if tallies else OUT_DISTANCE,
+                                           pairs))

@@ -1,0 +1,155 @@
+/*
+ * distance_hip.h — C ABI of libdistance_hip.so, the MI355X (gfx950) all-pairs genetic-distance
+ * engine.  Drop-in for the hot path of benjamincjackson/distance: everything between
+ * set_up()'s outputs and gather_write()'s input (src/lib.rs:269-474, 502-596), i.e. the pair
+ * generator + worker pools that call `fn(&EncodedFastaRecord, &EncodedFastaRecord) -> FloatInt`
+ * (src/lib.rs:477-488, call sites src/lib.rs:325 and :434).
+ *
+ * The reference has no FFI of its own; INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add.  Everything here is POD: plain pointers and sizes, no C++/torch types.
+ *
+ * Conventions
+ *  - every entry point returns a dst_status (0 = ok) and never throws or aborts;
+ *    dst_last_error() gives the message of the last failure on that context.
+ *  - a context is bound to ONE GPU and is single-owner (not re-entrant).  One process per GPU.
+ *  - the caller owns every pointer it passes; host pointers are not retained after return.
+ *  - "codes" are Paradis bytes exactly as src/encoding.rs:4-41 produces them (17 valid values);
+ *    any other byte is rejected by dst_upload* with DST_ERR_INVALID_CODE (the reference rejects
+ *    the character earlier, in encode(), src/fastaio.rs:111-113).
+ *  - canonical pair order = the reference's: square i<j row-major (src/lib.rs:511-512),
+ *    rectangle i outer / j inner (src/lib.rs:560-561).  Stream mode (src/lib.rs:322-331:
+ *    streamed record outer, loaded record inner) is a rectangle run with the streamed batch as
+ *    the row set, because every measure is symmetric in its two records.
+ */
+#ifndef DISTANCE_HIP_H
+#define DISTANCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DST_ABI_VERSION 1
+
+typedef struct dst_ctx dst_ctx;
+
+/* -m values, src/lib.rs:104-109; dispatch table of get_distance_function, src/lib.rs:477-488 */
+typedef enum {
+    DST_N = 0,      /* snp_consensus, src/measures.rs:28-53 (same integers as n_high, computed densely) */
+    DST_N_HIGH = 1, /* snp,           src/measures.rs:14-23  */
+    DST_RAW = 2,    /* raw,           src/measures.rs:56-69  */
+    DST_JC69 = 3,   /* jc69,          src/measures.rs:72-77  */
+    DST_K80 = 4,    /* k80,           src/measures.rs:80-113 */
+    DST_TN93 = 5    /* tn93,          src/measures.rs:116-193 */
+} dst_measure;
+
+typedef enum {
+    DST_OK = 0,
+    DST_ERR_ARG = 1,          /* bad argument / null pointer / range */
+    DST_ERR_HIP = 2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    DST_ERR_INVALID_CODE = 3, /* a byte that src/encoding.rs never produces */
+    DST_ERR_STATE = 4,        /* set not uploaded, widths differ (src/fastaio.rs:93-95), ... */
+    DST_ERR_NOMEM = 5,
+    DST_ERR_CAPACITY = 6      /* output buffer too small */
+} dst_status;
+
+/* What a run writes per pair, in canonical order:
+ *  DST_OUT_DISTANCE: 8 bytes — the payload of FloatInt (src/measures.rs:5-9): int64 for n/n_high,
+ *                    f64 for raw/jc69/k80/tn93 finalised ON DEVICE (reference operation order,
+ *                    ocml log/sqrt: within 1e-12 of the reference, not bit-identical).
+ *  DST_OUT_TALLY:    dst_tally_width(measure) x uint32 site tallies, bit-exact integers:
+ *                      n, n_high : {d}
+ *                      raw, jc69 : {n, d}                        (src/measures.rs:57-66)
+ *                      k80       : {count_L, ts, tv}             (src/measures.rs:81-107)
+ *                      tn93      : {count_L, count_d, count_P1, count_P2} (src/measures.rs:150-175)
+ *                    finalise with dst_finalize() on the host for bit-identical TSV text. */
+typedef enum { DST_OUT_DISTANCE = 0, DST_OUT_TALLY = 1 } dst_output;
+
+/* ---- library ------------------------------------------------------------------------- */
+int dst_abi_version(void);
+int dst_device_count(int *count);
+/* name -> dst_measure, or -1 (src/lib.rs:477-488 panics on unknown names; clap rejects first) */
+int dst_measure_from_name(const char *name);
+int dst_tally_width(int measure);
+const char *dst_status_string(int status);
+
+/* ---- context -------------------------------------------------------------------------- */
+int dst_create(int device, dst_ctx **ctx);
+int dst_destroy(dst_ctx *ctx);
+const char *dst_last_error(const dst_ctx *ctx); /* ctx may be NULL: last dst_create failure */
+/* upper bound, in bytes, of the device scratch one pair-kernel launch may use for tallies
+ * (default 32 GiB; runs are cut into row slabs that fit) */
+int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes);
+/* kernel tile variant: 0 = default for the measure; see DESIGN.md "tile variants" */
+int dst_set_variant(dst_ctx *ctx, int variant);
+
+/* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */
+/* codes: row-major n x len Paradis bytes, rows row_stride bytes apart (>= len).
+ * base_counts: n x 4 {A, T, G, C} per-record counts for tn93 (src/fastaio.rs:53-66, or the
+ * streamed variant src/fastaio.rs:136-142), or NULL to have them counted on device by code.
+ * slot is 0 or 1.  Both slots must have the same len (src/fastaio.rs:206-208). */
+int dst_upload(dst_ctx *ctx, int slot, const uint8_t *codes, size_t n, size_t len,
+               size_t row_stride, const uint32_t *base_counts);
+/* same with codes / base_counts already in this GPU's memory; `stream` is a hipStream_t (NULL =
+ * the context's own stream).  Asynchronous on that stream except for the validity check. */
+int dst_upload_device(dst_ctx *ctx, int slot, const void *d_codes, size_t n, size_t len,
+                      size_t row_stride, const uint32_t *d_base_counts, void *stream);
+int dst_set_info(const dst_ctx *ctx, int slot, size_t *n, size_t *len);
+/* per-record {A,T,G,C} counts the device holds for `slot` (n x 4), copied to host */
+int dst_get_base_counts(dst_ctx *ctx, int slot, uint32_t *counts);
+
+/* ---- canonical order helpers (src/lib.rs:502-596) --------------------------------------- */
+uint64_t dst_square_pairs(uint64_t n);                   /* n(n-1)/2 */
+uint64_t dst_square_row_start(uint64_t n, uint64_t i);   /* index of pair (i, i+1) */
+/* cut rows [0, n) into `parts` contiguous ranges of near-equal PAIR count (square) — the
+ * multi-GPU partition.  bounds has parts+1 entries, bounds[0]=0, bounds[parts]=n. */
+int dst_partition_square(uint64_t n, int parts, uint64_t *bounds);
+int dst_partition_rect(uint64_t n_rows, int parts, uint64_t *bounds);
+
+/* ---- run: replaces generate_pairs_* + the worker pools (src/lib.rs:367-474, 269-365) ----- */
+/* All pairs (i, j), row_begin <= i < row_end, i < j < n of slot 0, canonical order, written to
+ * d_out (device memory) starting with pair (row_begin, row_begin+1).  Asynchronous on `stream`
+ * (hipStream_t; NULL = context stream, then the call synchronises before returning). */
+int dst_run_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,
+                   void *d_out, size_t out_capacity_bytes, void *stream);
+/* All pairs (i, j), i in rows [row_begin,row_end) of row_slot, j over every record of col_slot;
+ * out[(i-row_begin) * n_col + j].  Two loaded files: row_slot=0, col_slot=1 (src/lib.rs:432-433).
+ * Stream mode: row_slot = the streamed batch, col_slot = the loaded set (src/lib.rs:322-331). */
+int dst_run_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
+                 uint64_t row_end, int out_kind, void *d_out, size_t out_capacity_bytes,
+                 void *stream);
+/* host-buffer forms: run + copy back (h_out is ordinary or pinned host memory) */
+int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end,
+                        int out_kind, void *h_out, size_t out_capacity_bytes);
+int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
+                      uint64_t row_end, int out_kind, void *h_out, size_t out_capacity_bytes);
+/* bytes a run writes */
+size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs);
+/* milliseconds of the pair kernel(s) / the pack kernel of the most recent run / upload on this
+ * context, from HIP events recorded on the launch stream (bench.py's roofline leg) */
+int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *pack_ms);
+
+/* Diagnostic: the tile schedule one pair-kernel launch would use for rows [row_begin,row_end)
+ * against n_cols records — (i0, j0) per workgroup in launch order, idle fillers as i0 = 2^32-1.
+ * tile_rows/tile_cols receive the tile shape of (measure, variant).  ij may be NULL to query
+ * *count only.  Pure host code (no GPU needed). */
+int dst_plan_tiles(int square, uint64_t row_begin, uint64_t row_end, uint64_t n_cols, int measure,
+                   int variant, uint32_t *ij, size_t cap_tiles, size_t *count, int *tile_rows,
+                   int *tile_cols);
+
+/* ---- host finalisation in the reference's f64 operation order --------------------------- */
+/* tallies: dst_tally_width(measure) uint32 per pair.  q_counts/t_counts: {A,T,G,C} of record_1 /
+ * record_2 (tn93 only, else may be NULL).  Writes the FloatInt payload: *as_int for n/n_high,
+ * *as_float otherwise (glibc log/sqrt, -ffp-contract=off => bit-identical to src/measures.rs). */
+int dst_finalize(int measure, const uint32_t *tallies, const uint32_t *q_counts,
+                 const uint32_t *t_counts, double *as_float, int64_t *as_int);
+/* One TSV field as gather_write prints it (src/lib.rs:626-633): `{}` / `{:.12}` incl. Rust's
+ * "NaN", "inf", "-inf", "-0.000000000000".  Returns the length written (no NUL counted). */
+int dst_format_distance(int measure, double as_float, int64_t as_int, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISTANCE_HIP_H */

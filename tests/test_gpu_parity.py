@@ -1,0 +1,305 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: integer tallies / n / n_high bit-exact; device-finalised raw/jc69/k80/tn93
+within 1e-12 (absolute and relative) of the oracle; host-finalised values bit-identical."""
+import math
+
+import numpy as np
+import pytest
+
+import distance_amd as da
+import oracle
+from helpers import CODES, random_alignment, uniform_codes
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = da.Engine(0)
+    yield e
+    e.close()
+
+
+def assert_close(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), "NaN pattern differs"
+    inf = np.isinf(want)
+    assert np.array_equal(got[inf], want[inf]), "inf pattern differs"
+    ok = ~(nan_w | inf)
+    err = np.abs(got[ok] - want[ok])
+    assert np.all(err <= TOL), f"abs err {err.max()}"
+    assert np.all(err <= TOL * np.maximum(np.abs(want[ok]), 1e-300) + 1e-300) or np.all(err <= TOL)
+
+
+def oracle_tallies_square(measure, codes):
+    ij = oracle.pairs_square(len(codes))
+    w = oracle.N_TALLIES[measure]
+    return np.array([oracle.tallies(measure, codes[int(i)], codes[int(j)]) for i, j in ij],
+                    np.uint64).reshape(len(ij), w)
+
+
+def check_square(eng, codes, measures=ALL, counts=None):
+    eng.upload(0, codes, counts)
+    for m in measures:
+        want = oracle.all_pairs_square(m, codes, counts=None if counts is None else counts.astype(np.uint64))
+        got = eng.run_square(m)
+        if m in da.INT_MEASURES:
+            assert got.dtype == np.int64 and np.array_equal(got, want.astype(np.int64)), m
+        else:
+            assert_close(got, want)
+        tl = eng.run_square(m, tallies=True)
+        assert np.array_equal(tl.astype(np.uint64), oracle_tallies_square(m, codes)), m
+
+
+# ------------------------------------------------------------------------------------------
+def test_golden_vectors_through_the_gpu(eng, golden):
+    """The reference's own 15-bp pair (src/measures.rs:202-208) through the HIP path."""
+    for v in golden["measures"]:
+        q, t = oracle.encode(v["query"].encode()), oracle.encode(v["target"].encode())
+        eng.upload(0, np.stack([q, t]))
+        got = eng.run_square(v["measure"])
+        assert got.shape == (1,)
+        if "int" in v:
+            assert int(got[0]) == v["int"]
+        else:
+            assert abs(got[0] - float.fromhex(v["hex"])) <= TOL
+            tl = eng.run_square(v["measure"], tallies=True)[0]
+            host = da.finalize(v["measure"], tl, oracle.count_bases(q), oracle.count_bases(t))
+            assert host == float.fromhex(v["hex"])  # bit-identical via host finalisation
+
+
+def test_golden_tsv_through_the_gpu(eng, golden):
+    for v in golden["tsv"]:
+        ids1 = [r[0] for r in v["loaded"]]
+        a = np.stack([oracle.encode(r[1].encode()) for r in v["loaded"]])
+        eng.upload(0, a)
+        lines = ["sequence1\tsequence2\tdistance"]
+        if v["mode"] == "square":
+            d = eng.run_square(v["measure"])
+            for (i, j), x in zip(oracle.pairs_square(len(a)), d):
+                lines.append(f"{ids1[int(i)]}\t{ids1[int(j)]}\t{da.format_distance(v['measure'], x)}")
+        else:
+            other = v.get("streamed") or v["second"]
+            ids2 = [r[0] for r in other]
+            b = np.stack([oracle.encode(r[1].encode()) for r in other])
+            if v["mode"] == "stream":
+                d = eng.run_stream_batch(v["measure"], b)  # [streamed][loaded]
+                for s in range(len(b)):
+                    for i in range(len(a)):
+                        lines.append(f"{ids1[i]}\t{ids2[s]}\t{da.format_distance(v['measure'], d[s, i])}")
+            else:
+                eng.upload(1, b)
+                d = eng.run_rect(v["measure"])
+                for i in range(len(a)):
+                    for j in range(len(b)):
+                        lines.append(f"{ids1[i]}\t{ids2[j]}\t{da.format_distance(v['measure'], d[i, j])}")
+        assert "\n".join(lines) + "\n" == v["expected"], v
+
+
+def test_exhaustive_code_pairs(eng):
+    """All 17x17 ordered code pairs as sites of two records + every code against itself."""
+    q = np.repeat(CODES, len(CODES))
+    t = np.tile(CODES, len(CODES))
+    check_square(eng, np.stack([q, t]))
+    check_square(eng, np.stack([t, q, q]))
+
+
+@pytest.mark.parametrize("n,L,seed", [(2, 1, 0), (3, 31, 1), (5, 32, 2), (7, 33, 3), (9, 127, 4),
+                                      (4, 128, 5), (6, 129, 6), (33, 257, 7), (70, 1000, 8)])
+def test_square_small_shapes(eng, n, L, seed):
+    check_square(eng, random_alignment(n, L, seed))
+
+
+def test_square_uniform_codes_and_tile_edges(eng):
+    # every code equally likely: exercises ambiguity / gap predicates at every site
+    check_square(eng, uniform_codes(40, 515, 11))
+    # crosses the 512/1024-column tile edges and several row tiles
+    codes = random_alignment(1030, 300, 12, divergence=0.2)
+    check_square(eng, codes, measures=("n_high", "raw", "tn93"))
+
+
+def test_single_record_and_identical_records(eng):
+    one = random_alignment(1, 100, 1)
+    eng.upload(0, one)
+    assert eng.run_square("raw").shape == (0,)
+    same = np.repeat(random_alignment(1, 300, 2, p_ambig=0, p_gap=0), 3, axis=0)
+    eng.upload(0, same)
+    assert np.array_equal(eng.run_square("n_high"), np.zeros(3, np.int64))
+    jc = eng.run_square("jc69")
+    assert np.all(jc == 0.0) and np.all(np.signbit(jc))          # -0.0 like the reference
+    tn = eng.run_square("tn93")
+    assert np.all(tn == 0.0) and not np.any(np.signbit(tn))       # measures.rs:188-190
+    allN = np.full((2, 77), 240, np.uint8)
+    eng.upload(0, allN)
+    assert math.isnan(eng.run_square("raw")[0])                   # 0/0
+    assert eng.run_square("n")[0] == 0
+
+
+def test_nan_inf_cases_match(eng):
+    a = oracle.encode(b"ACGTACGTACGTACGTAAAA")
+    b = oracle.encode(b"CATGCATGCATGCATGAAAA")   # p = 0.8 -> jc69 NaN
+    c = oracle.encode(b"CATGCATGCATGCATAAAAA")   # p = 0.75 -> jc69 +inf
+    check_square(eng, np.stack([a, b, c]), measures=("raw", "jc69", "k80", "tn93"))
+
+
+def test_row_ranges_and_partition_concatenate(eng):
+    codes = random_alignment(300, 200, 21)
+    eng.upload(0, codes)
+    for m in ("n_high", "raw", "tn93"):
+        full = eng.run_square(m)
+        for parts in (2, 3, 8):
+            b = da.partition_square(300, parts)
+            cat = np.concatenate([eng.run_square(m, b[k], b[k + 1]) for k in range(parts)])
+            assert np.array_equal(cat, full, equal_nan=True), (m, parts)
+        assert np.array_equal(eng.run_square(m, 17, 18), full[da.square_row_start(300, 17):
+                                                              da.square_row_start(300, 18)], equal_nan=True)
+        assert eng.run_square(m, 5, 5).shape == (0,)
+
+
+def test_slabs_give_identical_output(eng):
+    codes = random_alignment(200, 150, 22)
+    eng.upload(0, codes)
+    full = {m: eng.run_square(m) for m in ("raw", "tn93")}
+    eng.set_scratch_limit(4096)   # forces many row slabs through the tally scratch
+    try:
+        for m in full:
+            assert np.array_equal(eng.run_square(m), full[m], equal_nan=True)
+    finally:
+        eng.set_scratch_limit(32 << 30)
+
+
+def test_every_tile_variant_agrees(eng):
+    codes = random_alignment(600, 260, 23, divergence=0.3)
+    eng.upload(0, codes)
+    for m in ("n_high", "raw", "k80", "tn93"):
+        ref = None
+        for variant in range(4):
+            eng.set_variant(variant)
+            got = eng.run_square(m, tallies=True)
+            ref = got if ref is None else ref
+            assert np.array_equal(got, ref), (m, variant)
+        eng.set_variant(0)
+        assert np.array_equal(ref.astype(np.uint64), oracle_tallies_square(m, codes))
+
+
+def test_rectangle_and_stream_orders(eng):
+    a = random_alignment(37, 333, 31)
+    b = random_alignment(21, 333, 32)
+    eng.upload(0, a)
+    eng.upload(1, b)
+    for m in ALL:
+        want = oracle.all_pairs_rect(m, a, b)
+        got = eng.run_rect(m)                    # two loaded files: lib.rs:432-433
+        if m in da.INT_MEASURES:
+            assert np.array_equal(got, want.astype(np.int64))
+        else:
+            assert_close(got, want)
+        assert np.array_equal(eng.run_rect(m, row_begin=5, row_end=9), got[5:9], equal_nan=True)
+    for m in ("n_high", "raw", "tn93"):
+        want = oracle.all_pairs_rect(m, a, b)
+        got = eng.run_stream_batch(m, b)         # streamed-major: lib.rs:322-331
+        assert got.shape == (21, 37)
+        if m in da.INT_MEASURES:
+            assert np.array_equal(got, want.T.astype(np.int64))
+        else:
+            assert_close(got, want.T)
+
+
+def test_streamed_tn93_uses_caller_base_counts(eng):
+    """stream_fasta counts only upper-case raw characters (src/fastaio.rs:136-142)."""
+    loaded = [b"ACGTACGTAC", b"ACGTTCGTAC"]
+    streamed = [b"acgtACGTAC", b"ACGTACGTaa"]
+    a = np.stack([oracle.encode(s) for s in loaded])
+    enc = [oracle.encode_count_bases(s) for s in streamed]
+    b = np.stack([e[0] for e in enc])
+    bc = np.stack([e[1] for e in enc])
+    eng.upload(0, a)
+    got = eng.run_stream_batch("tn93", b, bc.astype(np.uint32))
+    ac = oracle.count_bases_matrix(a)
+    for s in range(2):
+        for i in range(2):
+            want = oracle.pair_distance("tn93", a[i], b[s], q_counts=ac[i], t_counts=bc[s])
+            assert abs(got[s, i] - want) <= TOL or (math.isnan(want) and math.isnan(got[s, i]))
+
+
+def test_base_counts_on_device(eng):
+    codes = uniform_codes(50, 777, 41)
+    eng.upload(0, codes)
+    assert np.array_equal(eng.base_counts(0).astype(np.uint64), oracle.count_bases_matrix(codes))
+
+
+def test_invalid_codes_are_rejected(eng):
+    valid = set(int(c) for c in CODES)
+    bad_values = [b for b in range(256) if b not in valid]
+    base = random_alignment(5, 300, 51)
+    for b in bad_values:
+        codes = base.copy()
+        codes[3, 257] = b
+        with pytest.raises(da.DistanceError) as ei:
+            eng.upload(0, codes)
+        assert ei.value.status == 3 and "record 3 at site 257" in ei.value.message, b
+    for c in CODES:   # and every valid code is accepted anywhere
+        codes = base.copy()
+        codes[:, ::7] = c
+        eng.upload(0, codes)
+    with pytest.raises(da.DistanceError):
+        eng.upload(0, np.zeros((0, 10), np.uint8))           # "Empty FASTA file"
+
+
+def test_width_mismatch_and_missing_set_errors(eng):
+    eng.upload(0, random_alignment(4, 100, 61))
+    eng.upload(1, random_alignment(4, 101, 62))
+    with pytest.raises(da.DistanceError) as ei:
+        eng.run_rect("raw")
+    assert "Different length sequences in alignment(s): 100 vs 101" in ei.value.message
+    fresh = da.Engine(0)
+    with pytest.raises(da.DistanceError):
+        fresh.run_square("raw")
+    fresh.close()
+
+
+def test_strided_and_unaligned_rows(eng):
+    big = random_alignment(9, 1000, 71)
+    view = big[:, 3:870]                       # row stride 1000, offset 3: unaligned rows
+    eng.upload(0, view)
+    want = oracle.all_pairs_square("raw", np.ascontiguousarray(view))
+    assert_close(eng.run_square("raw"), want)
+
+
+def test_large_shape_properties(eng):
+    """BASELINE-sized rows (L = 30,000) on a few thousand records: size-independent properties
+    plus a sampled oracle check."""
+    n, L = 3000, 30000
+    codes = random_alignment(n, L, 81, p_ambig=1e-3, p_gap=1e-3, divergence=1e-3)
+    eng.upload(0, codes)
+    tl = eng.run_square("raw", tallies=True)
+    nh = eng.run_square("n_high")
+    assert tl.shape == (n * (n - 1) // 2, 2)
+    assert np.array_equal(tl[:, 0].astype(np.int64), nh)          # raw's n == n_high
+    assert np.all(tl[:, 1] >= tl[:, 0]) and np.all(tl[:, 1] <= L)
+    raw = eng.run_square("raw")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert_close(raw, tl[:, 0] / tl[:, 1].astype(np.float64))
+    # symmetric rectangle of the set against itself == square entries, both triangles
+    eng.upload(1, codes[:64])
+    rect = eng.run_rect("n_high", row_slot=1, col_slot=0)
+    for i in range(0, 64, 9):
+        for j in range(i + 1, n, 371):
+            assert rect[i, j] == nh[da.square_row_start(n, i) + j - i - 1]
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        i = int(rng.integers(0, n - 1))
+        j = int(rng.integers(i + 1, n))
+        p = da.square_row_start(n, i) + j - i - 1
+        assert list(tl[p]) == list(oracle.tallies("raw", codes[i], codes[j]))
+    tn = eng.run_square("tn93", 100, 110)
+    counts = oracle.count_bases_matrix(codes[100:110])
+    p0 = da.square_row_start(n, 100)
+    for j in (101, 999, 2999):
+        want = oracle.pair_distance("tn93", codes[100], codes[j], q_counts=counts[0])
+        assert abs(tn[da.square_row_start(n, 100) + j - 101 - p0] - want) <= TOL
