@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py — all-pairs genetic-distance throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over the whole synthetic alignment, starting from the
+row-major N x L Paradis byte matrix resident in HBM: bit-plane pack -> pair-tile kernel ->
+finalise to f64 distances in canonical order (-> for N>1, every rank's slab sent straight to
+rank 0 over RCCL).  Prints ONE JSON line (rank 0).  `value` = pairs of the whole job / step time.
+
+Default workload: 50,000 x 30,000, -m raw — the shape the north-star target is quoted on.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import distance_amd as da
+from distance_amd.multi import gather_slabs, slab_layout
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
+HBM_COPY_GBS = 6290.0
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes x clock
+
+WORKLOADS = {
+    # name: (n, L, measure) — BASELINE.json configs
+    "C2": (10_000, 30_000, "raw"),
+    "C3": (50_000, 30_000, "tn93"),
+    "C3raw": (50_000, 30_000, "raw"),     # north-star target kernel at the C3 shape (default)
+    "C5": (200_000, 1_000, "jc69"),
+}
+OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  # VALU ops / 32 sites
+
+
+def synth_alignment(n: int, L: int, seed: int, device) -> torch.Tensor:
+    """SURVEY §8d synthetic alignment as Paradis codes, generated on the GPU in row chunks:
+    root with P(A,C,G,T)=(.30,.18,.20,.32); per-site substitution rate 1/1000 per record
+    (~Poisson(L/1000) per record); N w.p. 1e-3; 2-/3-fold IUPAC code w.p. 1e-4; 1 % of records
+    get leading and trailing '-' runs of U[0,200] sites."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    base = torch.tensor([136, 40, 72, 24], dtype=torch.uint8, device=device)          # A C G T
+    iupac = torch.tensor([192, 160, 144, 96, 80, 48, 224, 176, 208, 112], dtype=torch.uint8, device=device)
+    probs = torch.tensor([0.30, 0.18, 0.20, 0.32], device=device)
+    root_idx = torch.multinomial(probs, L, replacement=True, generator=g)
+    codes = torch.empty((n, L), dtype=torch.uint8, device=device)
+    chunk = max(1, min(n, (256 << 20) // max(L, 1)))
+    pos = torch.arange(L, device=device)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        rows = r1 - r0
+        u = torch.rand((rows, L), device=device, generator=g)
+        idx = root_idx.expand(rows, L)
+        shift = torch.randint(1, 4, (rows, L), device=device, generator=g, dtype=torch.int64)
+        idx = torch.where(u < 1e-3, (idx + shift) % 4, idx)
+        c = base[idx]
+        u2 = torch.rand((rows, L), device=device, generator=g)
+        c = torch.where(u2 < 1e-3, torch.full_like(c, 240), c)
+        amb = iupac[torch.randint(0, 10, (rows, L), device=device, generator=g)]
+        c = torch.where((u2 >= 1e-3) & (u2 < 1.1e-3), amb, c)
+        gap_rows = torch.rand(rows, device=device, generator=g) < 0.01
+        lead = torch.randint(0, 201, (rows,), device=device, generator=g) * gap_rows
+        trail = torch.randint(0, 201, (rows,), device=device, generator=g) * gap_rows
+        gap = (pos[None, :] < lead[:, None]) | (pos[None, :] >= (L - trail)[:, None])
+        c = torch.where(gap, torch.full_like(c, 244), c)
+        codes[r0:r1] = c
+        del u, u2, idx, shift, c, amb, gap
+    return codes
+
+
+def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 12.0) -> dict:
+    """The oracle (restated reference algorithm, C, pthreads) timed on this box's host cores on a
+    bounded sample of the same workload: the leading pairs of the canonical order."""
+    import oracle
+    cores = os.cpu_count() or 1
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    n = codes_host.shape[0]
+    total = n * (n - 1) // 2
+    t0 = time.perf_counter()
+    probe = min(total, 4000 * cores)
+    oracle.all_pairs_square(measure, codes_host, threads=cores, pair_range=(0, probe), native=native)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    sample = int(min(total, max(probe, probe * target_seconds / dt)))
+    t0 = time.perf_counter()
+    oracle.all_pairs_square(measure, codes_host, threads=cores, pair_range=(0, sample), native=native)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} canonical pairs of the same alignment ({n} x {codes_host.shape[1]} "
+                      f"host slice), -m {measure}, {dt:.1f} s, oracle/distance_oracle.c "
+                      f"({'-O3 -march=native' if native else '-O2'}), {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3raw", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override record count")
+    ap.add_argument("--len", type=int, default=0, help="override alignment width")
+    ap.add_argument("--measure", default="", help="override measure")
+    ap.add_argument("--variant", type=int, default=0, help="pair-kernel tile variant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements")
+    ap.add_argument("--seed", type=int, default=0xD157A2CE)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, L, measure = WORKLOADS[args.workload]
+    n = args.n or n
+    L = args.len or L
+    measure = args.measure or measure
+    total_pairs = n * (n - 1) // 2
+
+    # All GPU work (torch's generator / gather and the engine's kernels) runs on ONE explicit
+    # non-default stream: a NULL stream handle means "the context's own stream" to the C ABI.
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
+    codes = synth_alignment(n, L, args.seed, dev)      # every rank: the full replicated set
+    eng = da.Engine(local_rank)
+    eng.set_variant(args.variant)
+
+    bounds, offsets = slab_layout(n, world, square=True)
+    rb, re = bounds[rank], bounds[rank + 1]
+    my_pairs = offsets[rank + 1] - offsets[rank]
+    out_dtype = torch.int64 if measure in da.INT_MEASURES else torch.float64
+    local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+    full_out = local_out if world == 1 else (
+        torch.empty(total_pairs, dtype=out_dtype, device=dev) if rank == 0 else None)
+
+    def step():
+        eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+        eng.run_square_device(measure, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+        if world > 1:
+            gather_slabs(local_out, offsets, full_out, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    pair_ms, fin_ms, pack_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms = eng.last_kernel_ms()     # HIP events recorded on the launch stream
+        pair_ms.append(ms["pair_ms"])
+        fin_ms.append(ms["finalize_ms"])
+        pack_ms.append(ms["pack_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = total_pairs / (elapsed / args.steps)
+
+    if rank == 0:
+        # roofline of the dominant kernel (pair_kernel): algorithmic bytes per launch = pairs of
+        # the launch x (2L read + 8 written); duration = HIP events around the launch
+        k_ms = float(np.mean(pair_ms))
+        algo_bytes = my_pairs * (2 * L + 8)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        words = (L + 127) // 128 * 4
+        lane_ops = my_pairs * words * OPS_PER_WORD[measure] / (k_ms * 1e-3)
+        result = {
+            "metric": "pairwise comparisons/sec",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order"
+                                   f"{', RCCL send/recv of slabs to rank 0' if world > 1 else ''})",
+                       "name": args.workload, "n": n, "len": L, "measure": measure,
+                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count",
+                       "variant": args.variant},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pair_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+                         "note": "algorithmic bytes = pairs x (2L + 8); tiles reuse rows from LDS/registers, so "
+                                 "this exceeds physical HBM traffic (profiles/ has FETCH_SIZE); the true limiter "
+                                 "is VALU issue"},
+            "valu": {"achieved_lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                     "frac": lane_ops / VALU_PEAK_LANE_OPS, "ops_per_32_sites": OPS_PER_WORD[measure]},
+            "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms, "finalize": float(np.mean(fin_ms))},
+            "site_compares_per_s": value * L,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rows = min(n, 4000)
+            host = codes[:rows].cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(host, measure)
+        if world == 1 and not args.no_extra:
+            extra = {}
+            for name, m2 in (("tn93", "tn93"), ("n_high", "n_high")):
+                if m2 == measure:
+                    continue
+                eng.run_square_device(m2, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.run_square_device(m2, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                extra[f"{name}_pairs_per_s"] = total_pairs / dt
+            result["extra_untimed_region"] = extra
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing: one process per GPU, pair space cut into contiguous canonical ranges
+(row ranges of near-equal pair count), one exchange step at the end — every rank sends its
+result slab straight to rank 0 (grouped send/recv: on the nccl backend that is RCCL
+ncclSend/ncclRecv, peer -> root over xGMI on all links at once; never a ring).
+
+torch.distributed is plumbing only; the same code runs on gloo/CPU tensors in the tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .engine import partition_rect, partition_square, square_row_start
+
+
+def slab_layout(n: int, world: int, square: bool = True, n_cols: int | None = None):
+    """Row bounds and canonical pair offsets of each rank's slab.
+
+    Returns (bounds, offsets): rank r owns rows [bounds[r], bounds[r+1]) and canonical pair
+    indices [offsets[r], offsets[r+1])."""
+    if square:
+        bounds = partition_square(n, world)
+        offsets = [square_row_start(n, b) for b in bounds]
+    else:
+        bounds = partition_rect(n, world)
+        offsets = [b * int(n_cols) for b in bounds]
+    return bounds, offsets
+
+
+def gather_slabs(local: torch.Tensor, offsets: list[int], full: torch.Tensor | None, dst: int = 0,
+                 group=None):
+    """Send this rank's slab (1-D, or 2-D with pairs along dim 0) to `dst`, which receives every
+    slab directly into its place in `full` (no staging copy).  Returns the list of work handles
+    already waited on.  Contiguous canonical ranges make `full` ordered by construction."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ops = []
+    if rank == dst:
+        if full is None:
+            raise ValueError("rank dst needs the full output tensor")
+        lo, hi = offsets[dst], offsets[dst + 1]
+        if hi > lo:
+            full[lo:hi].copy_(local[: hi - lo])
+        for r in range(world):
+            if r == dst or offsets[r + 1] == offsets[r]:
+                continue
+            ops.append(dist.P2POp(dist.irecv, full[offsets[r]:offsets[r + 1]], r, group))
+    else:
+        count = offsets[rank + 1] - offsets[rank]
+        if count > 0:
+            ops.append(dist.P2POp(dist.isend, local[:count], dst, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return ops

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 and 3 on gloo: the multi-GPU partition + gather plumbing with the oracle
+standing in for each rank's compute (the GPU engine itself is covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, L, measure, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from distance_amd.multi import gather_slabs, slab_layout
+    from helpers import random_alignment
+
+    codes = random_alignment(n, L, seed=123)          # every rank holds the full set (replicated)
+    bounds, offsets = slab_layout(n, world, square=True)
+    lo, hi = offsets[rank], offsets[rank + 1]
+    local = torch.from_numpy(oracle.all_pairs_square(measure, codes, pair_range=(lo, hi)))
+    full = torch.full((offsets[-1],), -7.0, dtype=torch.float64) if rank == 0 else None
+    gather_slabs(local, offsets, full, dst=0)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 41), (3, 10), (2, 2)])
+def test_partition_and_gather_reassemble_canonical_order(tmp_path, world, n):
+    import oracle
+    from helpers import random_alignment
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n, 120, "raw", out), nprocs=world, join=True)
+    got = np.load(out)
+    want = oracle.all_pairs_square("raw", random_alignment(n, 120, seed=123))
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_slab_layout_rect_and_square():
+    from distance_amd.multi import slab_layout
+    b, o = slab_layout(100, 4, square=True)
+    assert b[0] == 0 and b[-1] == 100 and o[0] == 0 and o[-1] == 4950
+    assert all(x <= y for x, y in zip(o, o[1:]))
+    b, o = slab_layout(10, 4, square=False, n_cols=7)
+    assert o == [x * 7 for x in b] and o[-1] == 70
