@@ -443,6 +443,8 @@ int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes)
     return DST_OK;
 }
 
+int dst_variant_count(int measure) { return variant_count(measure); }
+
 int dst_set_variant(dst_ctx *ctx, int variant)
 {
     if (!ctx || variant < 0)

@@ -278,7 +278,8 @@ __device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
 // =============================================================================================
 // pair kernel
 // =============================================================================================
-// One block = BM row records x 256*TN column records, 256 threads (4 waves), 2 blocks per CU.
+// One block = BM row records x 256*TN column records, 256 threads (4 waves), MINW blocks per CU
+// (MINW = waves per SIMD asked of the register allocator).
 // Per 128-site chunk:
 //   columns: each lane loads its TN records' NP plane words straight from HBM/L2 into VGPRs
 //            (16 B per lane, 1 KiB contiguous per wave-instruction) and keeps them for all BM rows;
@@ -286,8 +287,8 @@ __device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
 //            barrier per chunk; every lane reads the same 16 bytes (broadcast ds_read_b128), so
 //            LDS time is 4 cycles per plane per row per wave against 64*TN VALU cycles;
 //   tallies: BM*TN*NC accumulators live in VGPRs for the whole sweep over L.
-template <class M, int BM, int TN, bool INT_OUT>
-__global__ __launch_bounds__(256, 2) void pair_kernel(
+template <class M, int BM, int TN, int MINW, bool INT_OUT>
+__global__ __launch_bounds__(256, MINW) void pair_kernel(
     const uint4 *__restrict__ qpl, const uint4 *__restrict__ tpl,
     const BlockDesc *__restrict__ blocks, uint32_t *__restrict__ tallies,
     int64_t *__restrict__ int_out, uint32_t nchunks, uint32_t q_npad, uint32_t t_npad,
@@ -521,18 +522,19 @@ hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream)
 namespace {
 
 struct Variant {
-    int bm, tn;
+    int bm, tn, minw;  // rows per tile, columns per lane, waves per SIMD asked of the register allocator
 };
 // tile variants per measure family; [0] is the default.  DESIGN.md "tile variants".
-constexpr Variant kVarNHigh[] = {{32, 4}, {64, 2}, {32, 2}, {16, 4}};
-constexpr Variant kVarRaw[] = {{32, 2}, {16, 4}, {16, 2}, {24, 2}};
-constexpr Variant kVarK80[] = {{16, 2}, {8, 2}, {12, 2}};
-constexpr Variant kVarTN93[] = {{16, 2}, {8, 4}, {12, 2}};
+// [0] is the default: picked on MI355X with tools/kbench.py (profiles/r01/kbench.txt)
+constexpr Variant kVarNHigh[] = {{24, 2, 4}, {16, 2, 4}, {32, 2, 3}, {64, 2, 2}, {32, 4, 2}, {16, 4, 3}};
+constexpr Variant kVarRaw[] = {{12, 2, 4}, {16, 2, 3}, {8, 2, 4}, {32, 2, 2}, {24, 2, 2}, {16, 4, 2}};
+constexpr Variant kVarK80[] = {{12, 2, 3}, {8, 2, 3}, {16, 2, 2}, {10, 2, 4}};
+constexpr Variant kVarTN93[] = {{12, 2, 3}, {8, 2, 4}, {16, 2, 2}, {8, 4, 2}, {10, 2, 4}};
 
-template <class M, int BM, int TN, bool INT_OUT>
+template <class M, int BM, int TN, int MINW, bool INT_OUT>
 hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
 {
-    hipLaunchKernelGGL((pair_kernel<M, BM, TN, INT_OUT>), dim3(pl.nblocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((pair_kernel<M, BM, TN, MINW, INT_OUT>), dim3(pl.nblocks), dim3(256), 0, stream,
                        pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_tallies, pl.d_int_out,
                        (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad, (uint32_t)pl.cols->npad,
                        (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, (uint32_t)pl.row_end,
@@ -555,52 +557,57 @@ int variant_count(int measure)
     }
 }
 
-TileShape tile_shape(int measure, int variant)
+static Variant pick_variant(int measure, int variant)
 {
     const int nv = variant_count(measure);
     if (variant < 0 || variant >= nv)
         variant = 0;
-    Variant v{32, 1};
     switch (measure) {
     case DST_N:
-    case DST_N_HIGH: v = kVarNHigh[variant]; break;
+    case DST_N_HIGH: return kVarNHigh[variant];
     case DST_RAW:
-    case DST_JC69: v = kVarRaw[variant]; break;
-    case DST_K80: v = kVarK80[variant]; break;
-    case DST_TN93: v = kVarTN93[variant]; break;
-    default: break;
+    case DST_JC69: return kVarRaw[variant];
+    case DST_K80: return kVarK80[variant];
+    default: return kVarTN93[variant];
     }
+}
+
+TileShape tile_shape(int measure, int variant)
+{
+    const Variant v = pick_variant(measure, variant);
     return TileShape{v.bm, 256 * v.tn};
 }
 
-#define DST_CASE(M, BM_, TN_, IO)                                   \
-    if (ts.bm == BM_ && ts.bn == 256 * TN_)                         \
-        return launch_one<M, BM_, TN_, IO>(pl, stream);
+#define DST_CASE(M, BM_, TN_, W_, IO)                               \
+    if (v.bm == BM_ && v.tn == TN_ && v.minw == W_)                 \
+        return launch_one<M, BM_, TN_, W_, IO>(pl, stream);
 
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream)
 {
-    const TileShape ts = tile_shape(measure, variant);
+    const Variant v = pick_variant(measure, variant);
     switch (measure) {
     case DST_N:
     case DST_N_HIGH:
         if (pl.d_int_out) {
-            DST_CASE(MNHigh, 32, 4, true) DST_CASE(MNHigh, 64, 2, true)
-            DST_CASE(MNHigh, 32, 2, true) DST_CASE(MNHigh, 16, 4, true)
+            DST_CASE(MNHigh, 16, 2, 4, true) DST_CASE(MNHigh, 32, 2, 3, true) DST_CASE(MNHigh, 24, 2, 4, true)
+            DST_CASE(MNHigh, 64, 2, 2, true) DST_CASE(MNHigh, 32, 4, 2, true) DST_CASE(MNHigh, 16, 4, 3, true)
         } else {
-            DST_CASE(MNHigh, 32, 4, false) DST_CASE(MNHigh, 64, 2, false)
-            DST_CASE(MNHigh, 32, 2, false) DST_CASE(MNHigh, 16, 4, false)
+            DST_CASE(MNHigh, 16, 2, 4, false) DST_CASE(MNHigh, 32, 2, 3, false) DST_CASE(MNHigh, 24, 2, 4, false)
+            DST_CASE(MNHigh, 64, 2, 2, false) DST_CASE(MNHigh, 32, 4, 2, false) DST_CASE(MNHigh, 16, 4, 3, false)
         }
         break;
     case DST_RAW:
     case DST_JC69:
-        DST_CASE(MRaw, 32, 2, false) DST_CASE(MRaw, 16, 4, false)
-        DST_CASE(MRaw, 16, 2, false) DST_CASE(MRaw, 24, 2, false)
+        DST_CASE(MRaw, 12, 2, 4, false) DST_CASE(MRaw, 16, 2, 3, false) DST_CASE(MRaw, 8, 2, 4, false)
+        DST_CASE(MRaw, 32, 2, 2, false) DST_CASE(MRaw, 24, 2, 2, false) DST_CASE(MRaw, 16, 4, 2, false)
         break;
     case DST_K80:
-        DST_CASE(MK80, 16, 2, false) DST_CASE(MK80, 8, 2, false) DST_CASE(MK80, 12, 2, false)
+        DST_CASE(MK80, 8, 2, 3, false) DST_CASE(MK80, 16, 2, 2, false) DST_CASE(MK80, 12, 2, 3, false)
+        DST_CASE(MK80, 10, 2, 4, false)
         break;
     case DST_TN93:
-        DST_CASE(MTN93, 16, 2, false) DST_CASE(MTN93, 8, 4, false) DST_CASE(MTN93, 12, 2, false)
+        DST_CASE(MTN93, 12, 2, 3, false) DST_CASE(MTN93, 8, 2, 4, false) DST_CASE(MTN93, 16, 2, 2, false)
+        DST_CASE(MTN93, 8, 4, 2, false) DST_CASE(MTN93, 10, 2, 4, false)
         break;
     default: break;
     }

@@ -84,6 +84,7 @@ const char *dst_last_error(const dst_ctx *ctx); /* ctx may be NULL: last dst_cre
 int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes);
 /* kernel tile variant: 0 = default for the measure; see DESIGN.md "tile variants" */
 int dst_set_variant(dst_ctx *ctx, int variant);
+int dst_variant_count(int measure);
 
 /* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */
 /* codes: row-major n x len Paradis bytes, rows row_stride bytes apart (>= len).

@@ -7,8 +7,8 @@ path = sys.argv[1] if len(sys.argv) > 1 else "build/asm/resource_usage.txt"
 txt = open(path).read()
 for b in re.split(r"remark: Function Name: ", txt)[1:]:
     name = b.split()[0]
-    m = re.search(r"pair_kernelINS0_(\w+?)ELi(\d+)ELi(\d+)ELb(\d)", name)
-    short = f"{m.group(1)} BM={m.group(2)} TN={m.group(3)} INT={m.group(4)}" if m else name[:70]
+    m = re.search(r"pair_kernelINS0_(\w+?)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
+    short = f"{m.group(1)} BM={m.group(2)} TN={m.group(3)} W={m.group(4)} INT={m.group(5)}" if m else name[:70]
 
     def g(key):
         mm = re.search(re.escape(key) + r": (\d+)", b)
