@@ -1,0 +1,683 @@
+// distance — drop-in CLI for benjamincjackson/distance on MI355X.
+//
+// Keeps the reference's surface (clap definition src/lib.rs:68-131, rules of set_up()
+// src/lib.rs:162-267): -i/--input (0..2 files) or positional files, -s/--stream (file or "-"),
+// -m/--measure {n,n_high,raw,jc69,k80,tn93} (default raw), -o/--output, -t/--threads,
+// -b/--batchsize, -l/--licenses, -h, -V; TSV output identical to gather_write()
+// (src/lib.rs:612-644).  The pair generators and worker pools (src/lib.rs:269-474, 502-596) are
+// replaced by libdistance_hip.so through its C ABI; -t sizes the host formatting pool and -b is
+// accepted — neither changes the output, as in the reference (src/lib.rs:919-1154).
+// Extra flags: --gpus N (default 1), --slab-pairs P (result slab size).
+//
+// Exactness: the GPU returns integer site tallies; f64 finalisation is dst_finalize() on the host
+// (reference operation order, glibc log/sqrt), so the printed digits do not depend on the device.
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <unistd.h>
+
+#include "../../include/distance_hip.h"
+#include "fasta.hpp"
+#include "format.hpp"
+
+namespace {
+
+const char *kVersion = "0.3.1";  // Cargo.toml:3 of the reference this CLI mirrors
+
+// ---------------------------------------------------------------- errors ----------------------
+// main() of the reference returns Result<(), DistanceError>: Rust prints `Error: {:?}` and exits 1.
+[[noreturn]] void die_message(const std::string &m)
+{
+    std::fprintf(stderr, "Error: Message(\"%s\")\n", m.c_str());
+    std::exit(1);
+}
+
+[[noreturn]] void die_io(const std::string &what, int err)
+{
+    std::fprintf(stderr, "Error: IOError(Os { code: %d, kind: %s, message: \"%s\" }) [%s]\n", err,
+                 err == ENOENT ? "NotFound" : err == EACCES ? "PermissionDenied" : "Other", std::strerror(err),
+                 what.c_str());
+    std::exit(1);
+}
+
+[[noreturn]] void die_usage(const std::string &m)
+{
+    std::fprintf(stderr, "error: %s\n\nFor more information, try '--help'.\n", m.c_str());
+    std::exit(2);  // clap's usage-error exit code
+}
+
+void print_help()
+{
+    std::puts(
+        "Calculate genetic distances within/between fasta-format alignments of DNA sequences\n\n"
+        "Usage: All sequences across all input files must be the same length.\n\n"
+        "       distance alignment.fasta\n"
+        "       cat alignment.fasta | distance\n"
+        "       distance alignment.fasta -o distances.tsv\n"
+        "       distance -t 8 -m jc69 alignment.fasta -o jc69.tsv\n"
+        "       distance alignment1.fasta alignment2.fasta > distances2.tsv\n"
+        "       distance -i smallAlignment.fasta -s bigAlignment.fasta -o distances3.tsv\n"
+        "       cat bigAlignment.fasta | distance smallAlignment.fasta -s - > distances3.tsv\n"
+        "       \n\n"
+        "Options:\n"
+        "  -i, --input [<input>...]     One or two input alignment files in fasta format. Loaded into memory. "
+        "This flag can be omitted and the files passed as positional arguments\n"
+        "  -s, --stream <stream>        One input alignment file in fasta format. Streamed from disk (or stdin "
+        "using \"-s -\"). Requires exactly one file also be loaded\n"
+        "  -m, --measure <measure>      Which distance measure to use [default: raw] [possible values: n, n_high, "
+        "raw, jc69, k80, tn93]\n"
+        "  -o, --output <output>        Output file in tab-separated-value format. Omit this option to print to "
+        "stdout\n"
+        "  -t, --threads <threads>      How many threads to spin up for pairwise comparisons. Omitting this option "
+        "spins up the number of available CPUs\n"
+        "  -b, --batchsize <batchsize>  Try setting this >(>) 1 to tune the workload per thread [default: 1]\n"
+        "  -l, --licenses               Print licence information and exit\n"
+        "      --gpus <n>               MI355X GPUs to use (default 1)\n"
+        "  -h, --help                   Print help\n"
+        "  -V, --version                Print version");
+}
+
+// ---------------------------------------------------------------- arguments -------------------
+struct Args {
+    std::vector<std::string> flag_inputs, pos_inputs;
+    bool has_stream = false;
+    std::string stream, measure = "raw", output;
+    bool has_output = false, has_threads = false, licenses = false;
+    size_t threads = 0, batchsize = 1;
+    int gpus = 1;
+    size_t slab_pairs = (size_t)1 << 24;
+    std::string selftest;
+};
+
+size_t parse_usize(const std::string &v, const char *flag)
+{
+    if (v.empty() || v.find_first_not_of("0123456789") != std::string::npos)
+        die_usage("invalid value '" + v + "' for '" + flag + "': invalid digit found in string");
+    errno = 0;
+    unsigned long long x = std::strtoull(v.c_str(), nullptr, 10);
+    if (errno)
+        die_usage("invalid value '" + v + "' for '" + flag + "': number too large to fit in target type");
+    return (size_t)x;
+}
+
+Args parse_args(int argc, char **argv)
+{
+    Args a;
+    auto value_of = [&](int &k, const std::string &arg, const char *flag) -> std::string {
+        const size_t eq = arg.find('=');
+        if (arg.rfind("--", 0) == 0 && eq != std::string::npos)
+            return arg.substr(eq + 1);
+        if (arg.rfind("--", 0) != 0 && arg.size() > 2)
+            return arg.substr(2);  // -mraw
+        if (k + 1 >= argc)
+            die_usage(std::string("a value is required for '") + flag + "' but none was supplied");
+        return argv[++k];
+    };
+    auto is = [](const std::string &arg, const char *s, const char *l) {
+        if (arg == l || arg.rfind(std::string(l) + "=", 0) == 0)
+            return true;
+        return arg.rfind(s, 0) == 0 && arg.rfind("--", 0) != 0;
+    };
+    bool only_pos = false;
+    for (int k = 1; k < argc; ++k) {
+        const std::string arg = argv[k];
+        if (only_pos || arg == "-" || arg.empty() || arg[0] != '-') {
+            a.pos_inputs.push_back(arg);
+            continue;
+        }
+        if (arg == "--") {
+            only_pos = true;
+        } else if (arg == "-h" || arg == "--help") {
+            print_help();
+            std::exit(0);
+        } else if (arg == "-V" || arg == "--version") {
+            std::printf("distance %s\n", kVersion);
+            std::exit(0);
+        } else if (arg == "-l" || arg == "--licenses") {
+            a.licenses = true;
+        } else if (is(arg, "-i", "--input")) {
+            // num_args(0..=2): takes following non-flag words, at most two
+            const size_t eq = arg.find('=');
+            if (arg.rfind("--", 0) == 0 && eq != std::string::npos)
+                a.flag_inputs.push_back(arg.substr(eq + 1));
+            else if (arg.rfind("--", 0) != 0 && arg.size() > 2)
+                a.flag_inputs.push_back(arg.substr(2));
+            while (a.flag_inputs.size() < 2 && k + 1 < argc && (argv[k + 1][0] != '-' || !std::strcmp(argv[k + 1], "-")))
+                a.flag_inputs.push_back(argv[++k]);
+        } else if (is(arg, "-s", "--stream")) {
+            a.stream = value_of(k, arg, "--stream <stream>");
+            a.has_stream = true;
+        } else if (is(arg, "-m", "--measure")) {
+            a.measure = value_of(k, arg, "--measure <measure>");
+        } else if (is(arg, "-o", "--output")) {
+            a.output = value_of(k, arg, "--output <output>");
+            a.has_output = true;
+        } else if (is(arg, "-t", "--threads")) {
+            a.threads = parse_usize(value_of(k, arg, "--threads <threads>"), "--threads <threads>");
+            a.has_threads = true;
+        } else if (is(arg, "-b", "--batchsize")) {
+            a.batchsize = parse_usize(value_of(k, arg, "--batchsize <batchsize>"), "--batchsize <batchsize>");
+        } else if (arg == "--gpus" || arg.rfind("--gpus=", 0) == 0) {
+            a.gpus = (int)parse_usize(value_of(k, arg, "--gpus <n>"), "--gpus <n>");
+        } else if (arg == "--slab-pairs" || arg.rfind("--slab-pairs=", 0) == 0) {
+            a.slab_pairs = std::max<size_t>(1, parse_usize(value_of(k, arg, "--slab-pairs <p>"), "--slab-pairs <p>"));
+        } else if (arg == "--host-selftest") {
+            a.selftest = value_of(k, arg, "--host-selftest <what>");
+        } else {
+            die_usage("unexpected argument '" + arg + "' found");
+        }
+    }
+    if (a.pos_inputs.size() > 2)
+        die_usage("unexpected argument '" + a.pos_inputs[2] + "' found");
+    if (dst_measure_from_name(a.measure.c_str()) < 0)
+        die_usage("invalid value '" + a.measure + "' for '--measure <measure>'\n  [possible values: n, n_high, raw, "
+                  "jc69, k80, tn93]");
+    return a;
+}
+
+const char *kLicences =
+    "\nCopyright 2022, Ben Jackson (distance, GNU LIBRARY GENERAL PUBLIC LICENSE, Version 2): this program is an\n"
+    "independent MI355X re-implementation of its command-line surface and output format.\n"
+    "FASTA tokenisation follows Rust-Bio (MIT licence, Copyright (c) 2016 Johannes Koester, the Rust-Bio team,\n"
+    "Google Inc.).  Nucleotide coding scheme: Emmanuel Paradis, as used in ape.\n";
+
+// ---------------------------------------------------------------- loading ---------------------
+// src/encoding.rs:4-41
+void encoding_array(uint8_t a[256])
+{
+    std::memset(a, 0, 256);
+    const char *letters = "AGCTRMWSKYVHDBN";
+    const uint8_t codes[] = {136, 72, 40, 24, 192, 160, 144, 96, 80, 48, 224, 176, 208, 112, 240};
+    for (int k = 0; letters[k]; ++k) {
+        a[(unsigned char)letters[k]] = codes[k];
+        a[(unsigned char)(letters[k] - 'A' + 'a')] = codes[k];
+    }
+    a[(unsigned char)'-'] = 244;
+    a[(unsigned char)'?'] = 242;
+}
+
+struct Alignment {
+    std::vector<std::string> ids;
+    std::vector<uint8_t> codes;      // n x width, row-major
+    std::vector<uint32_t> counts;    // n x 4 {A,T,G,C}: only filled for streamed tn93 batches
+    size_t n = 0, width = 0;
+};
+
+std::string err_invalid_nuc(const std::string &id, unsigned char c)  // src/fastaio.rs:89-91
+{
+    std::string s = "Invalid nucleotide character in record '" + id + "': '";
+    s.push_back((char)c);
+    return s + "'";
+}
+
+std::string err_lengths(size_t w1, size_t w2)  // src/fastaio.rs:93-95
+{
+    return "Different length sequences in alignment(s): " + std::to_string(w1) + " vs " + std::to_string(w2);
+}
+
+// encode() / encode_count_bases(): src/fastaio.rs:101-145
+void encode_into(const cli::FastaRecord &rec, const uint8_t *table, Alignment &al, bool count_raw_upper)
+{
+    const size_t at = al.codes.size();
+    al.codes.resize(at + rec.seq.size());
+    uint32_t counting[256];
+    if (count_raw_upper)
+        std::memset(counting, 0, sizeof counting);
+    for (size_t i = 0; i < rec.seq.size(); ++i) {
+        const unsigned char c = (unsigned char)rec.seq[i];
+        if (table[c] == 0)
+            die_message(err_invalid_nuc(rec.id, c));
+        al.codes[at + i] = table[c];
+        if (count_raw_upper)
+            counting[c] += 1;
+    }
+    if (count_raw_upper) {
+        al.counts.push_back(counting['A']);
+        al.counts.push_back(counting['T']);
+        al.counts.push_back(counting['G']);
+        al.counts.push_back(counting['C']);
+    }
+    al.ids.push_back(rec.id);
+    al.n += 1;
+}
+
+FILE *open_input(const std::string &path)
+{
+    FILE *fh = std::fopen(path.c_str(), "rb");
+    if (!fh)
+        die_io(path, errno);
+    return fh;
+}
+
+// load_fasta(): src/fastaio.rs:174-199
+Alignment load_fasta(FILE *fh, const uint8_t *table)
+{
+    Alignment al;
+    cli::FastaReader reader(fh);
+    cli::FastaRecord rec;
+    bool first = true;
+    for (;;) {
+        const int rc = reader.next(rec);
+        if (rc < 0)
+            die_message(reader.error());
+        if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty()))
+            break;  // bio's Records iterator stops at an empty record
+        encode_into(rec, table, al, false);
+        if (first) {
+            al.width = rec.seq.size();
+            first = false;
+        } else if (rec.seq.size() != al.width) {
+            die_message(err_lengths(rec.seq.size(), al.width));
+        }
+    }
+    if (al.n == 0)
+        die_message("Empty FASTA file");  // src/fastaio.rs:97-99
+    return al;
+}
+
+// ---------------------------------------------------------------- ordered output --------------
+struct Writer {
+    FILE *fh = stdout;
+    void write(const char *p, size_t n)
+    {
+        if (!n)
+            return;
+        if (std::fwrite(p, 1, n, fh) != n) {
+            if (errno == EPIPE)
+                std::exit(0);  // handle_broken_pipe(): src/lib.rs:598-608
+            die_io("write", errno);
+        }
+    }
+    void flush()
+    {
+        if (std::fflush(fh) != 0) {
+            if (errno == EPIPE)
+                std::exit(0);
+            die_io("flush", errno);
+        }
+    }
+};
+
+struct Ctx {
+    dst_ctx *h = nullptr;
+    void check(int rc, const char *what) const
+    {
+        if (rc != DST_OK) {
+            std::fprintf(stderr, "Error: Gpu(\"%s: %s\")\n", what, dst_last_error(h));
+            std::exit(1);
+        }
+    }
+};
+
+// One slab of results: rows [rb, re) of the row set against the column set (square: j > i).
+struct Slab {
+    uint64_t rb = 0, re = 0;
+    std::vector<uint32_t> tallies;
+    std::string text;
+};
+
+struct Job {
+    int measure = 0;
+    bool square = true;
+    bool swap_ids = false;            // stream mode: rows are the streamed batch, id1 is the loaded id
+    const Alignment *rows = nullptr;  // row set (ids + per-record counts)
+    const Alignment *cols = nullptr;
+    const uint32_t *row_counts = nullptr, *col_counts = nullptr;  // tn93 {A,T,G,C}
+    size_t fmt_threads = 1;
+};
+
+// tallies -> TSV text, in canonical order, split over the formatting pool (-t)
+void format_slab(const Job &job, Slab &slab)
+{
+    const int w = dst_tally_width(job.measure);
+    const uint64_t ncols = job.cols->n;
+    const uint64_t rows = slab.re - slab.rb;
+    const size_t T = std::max<size_t>(1, std::min<size_t>(job.fmt_threads, rows));
+    std::vector<std::string> parts(T);
+    // split rows so that each part has about the same number of pairs
+    std::vector<uint64_t> cut(T + 1, slab.re);
+    cut[0] = slab.rb;
+    {
+        auto pairs_before = [&](uint64_t r) -> uint64_t {
+            if (!job.square)
+                return (r - slab.rb) * ncols;
+            return dst_square_row_start(ncols, r) - dst_square_row_start(ncols, slab.rb);
+        };
+        const uint64_t total = pairs_before(slab.re);
+        uint64_t r = slab.rb;
+        for (size_t k = 1; k < T; ++k) {
+            const uint64_t target = total * k / T;
+            while (r < slab.re && pairs_before(r) < target)
+                ++r;
+            cut[k] = r;
+        }
+    }
+    auto work = [&](size_t k) {
+        std::string &out = parts[k];
+        char num[64];
+        for (uint64_t i = cut[k]; i < cut[k + 1]; ++i) {
+            const uint64_t j0 = job.square ? i + 1 : 0;
+            uint64_t p = job.square ? dst_square_row_start(ncols, i) - dst_square_row_start(ncols, slab.rb)
+                                    : (i - slab.rb) * ncols;
+            const std::string &row_id = job.rows->ids[i];
+            const uint32_t *rc = job.row_counts ? job.row_counts + 4 * i : nullptr;
+            for (uint64_t j = j0; j < ncols; ++j, ++p) {
+                double f = 0;
+                int64_t iv = 0;
+                const uint32_t *cc = job.col_counts ? job.col_counts + 4 * j : nullptr;
+                // record_1 = loaded / file-0 record, record_2 = the other (src/lib.rs:325, 432-434)
+                if (job.swap_ids)
+                    dst_finalize(job.measure, &slab.tallies[p * w], cc, rc, &f, &iv);
+                else
+                    dst_finalize(job.measure, &slab.tallies[p * w], rc, cc, &f, &iv);
+                const std::string &id1 = job.swap_ids ? job.cols->ids[j] : row_id;
+                const std::string &id2 = job.swap_ids ? row_id : job.cols->ids[j];
+                out.append(id1);
+                out.push_back('\t');
+                out.append(id2);
+                out.push_back('\t');
+                const int n = (job.measure == DST_N || job.measure == DST_N_HIGH) ? cli::fmt_i64(iv, num)
+                                                                                  : cli::fmt_fixed12(f, num);
+                out.append(num, (size_t)n);
+                out.push_back('\n');
+            }
+        }
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < T; ++k)
+            th.emplace_back(work, k);
+        work(0);
+        for (auto &t : th)
+            t.join();
+    }
+    size_t total = 0;
+    for (auto &s : parts)
+        total += s.size();
+    slab.text.clear();
+    slab.text.reserve(total);
+    for (auto &s : parts)
+        slab.text.append(s);
+}
+
+// rows [0, n_rows) cut into slabs of <= max_pairs pairs (at least one row each)
+std::vector<std::pair<uint64_t, uint64_t>> make_slabs(bool square, uint64_t n_rows, uint64_t n_cols, uint64_t max_pairs)
+{
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    uint64_t rb = 0;
+    const uint64_t last = square ? (n_rows ? n_rows - 1 : 0) : n_rows;  // the last square row has no pairs
+    while (rb < last) {
+        uint64_t re = rb, pairs = 0;
+        while (re < last) {
+            const uint64_t row_pairs = square ? n_cols - re - 1 : n_cols;
+            if (re > rb && pairs + row_pairs > max_pairs)
+                break;
+            pairs += row_pairs;
+            ++re;
+        }
+        out.emplace_back(rb, re);
+        rb = re;
+    }
+    return out;
+}
+
+// Compute every slab on the GPUs (slab k on GPU k mod G), format on the host pool, write in order.
+void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slot, uint64_t max_pairs, Writer &wr)
+{
+    const auto slabs = make_slabs(job.square, job.rows->n, job.cols->n, max_pairs);
+    const int w = dst_tally_width(job.measure);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Slab>> done;  // finished slabs, any order
+    size_t next_to_write = 0;
+    std::atomic<size_t> next_slab{0};
+    const size_t window = gpus.size() * 2 + 1;  // bound on slabs in flight (memory)
+    std::vector<std::unique_ptr<Slab>> ready(slabs.size());
+
+    auto gpu_worker = [&](size_t g) {
+        for (;;) {
+            const size_t k = next_slab.fetch_add(1);
+            if (k >= slabs.size())
+                return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return k < next_to_write + window; });
+            }
+            auto s = std::make_unique<Slab>();
+            s->rb = slabs[k].first;
+            s->re = slabs[k].second;
+            const uint64_t pairs = job.square ? dst_square_row_start(job.cols->n, s->re) - dst_square_row_start(job.cols->n, s->rb)
+                                              : (s->re - s->rb) * job.cols->n;
+            s->tallies.resize((size_t)pairs * w);
+            const int rc = job.square ? dst_run_square_host(gpus[g].h, job.measure, s->rb, s->re, DST_OUT_TALLY,
+                                                            s->tallies.data(), s->tallies.size() * 4)
+                                      : dst_run_rect_host(gpus[g].h, job.measure, row_slot, col_slot, s->rb, s->re,
+                                                          DST_OUT_TALLY, s->tallies.data(), s->tallies.size() * 4);
+            gpus[g].check(rc, "run");
+            format_slab(job, *s);
+            s->tallies.clear();
+            s->tallies.shrink_to_fit();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[k] = std::move(s);
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> workers;
+    for (size_t g = 0; g < gpus.size(); ++g)
+        workers.emplace_back(gpu_worker, g);
+    // ordered writer (the reference's gather_write re-orders by batch idx: src/lib.rs:616-637)
+    while (next_to_write < slabs.size()) {
+        std::unique_ptr<Slab> s;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[next_to_write] != nullptr; });
+            s = std::move(ready[next_to_write]);
+        }
+        wr.write(s->text.data(), s->text.size());
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ++next_to_write;
+        }
+        cv.notify_all();
+    }
+    for (auto &t : workers)
+        t.join();
+}
+
+// ---------------------------------------------------------------- host self-tests (no GPU) -----
+int host_selftest(const Args &a)
+{
+    if (a.selftest == "fasta") {  // parse stdin, print one line per record
+        uint8_t table[256];
+        encoding_array(table);
+        cli::FastaReader reader(stdin);
+        cli::FastaRecord rec;
+        for (;;) {
+            const int rc = reader.next(rec);
+            if (rc < 0) {
+                std::printf("ERROR\t%s\n", reader.error().c_str());
+                return 0;
+            }
+            if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty()))
+                break;
+            std::printf("%s\t%s\t%s\n", rec.id.c_str(), rec.has_desc ? rec.desc.c_str() : "<none>", rec.seq.c_str());
+        }
+        return 0;
+    }
+    if (a.selftest == "format") {  // hex floats on stdin -> {:.12}
+        char line[256], out[512];
+        while (std::fgets(line, sizeof line, stdin)) {
+            const double v = std::strtod(line, nullptr);
+            const int n = cli::fmt_fixed12(v, out);
+            out[n] = 0;
+            std::puts(out);
+        }
+        return 0;
+    }
+    if (a.selftest == "args") {
+        std::printf("measure=%s threads=%zu%s batchsize=%zu stream=%s output=%s gpus=%d inputs=", a.measure.c_str(),
+                    a.threads, a.has_threads ? "" : "(default)", a.batchsize, a.has_stream ? a.stream.c_str() : "<none>",
+                    a.has_output ? a.output.c_str() : "<stdout>", a.gpus);
+        for (auto &s : a.flag_inputs)
+            std::printf("[-i %s]", s.c_str());
+        for (auto &s : a.pos_inputs)
+            std::printf("[pos %s]", s.c_str());
+        std::puts("");
+        return 0;
+    }
+    die_usage("unknown --host-selftest");
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::signal(SIGPIPE, SIG_IGN);  // EPIPE is handled at the write (exit 0), like the reference
+    Args a = parse_args(argc, argv);
+    if (!a.selftest.empty())
+        return host_selftest(a);
+    if (a.licenses) {  // src/main.rs:7-10
+        std::puts(kLicences);
+        return 0;
+    }
+    // ---- set_up(): src/lib.rs:162-267 -------------------------------------------------------
+    if (!a.pos_inputs.empty() && !a.flag_inputs.empty())
+        die_message("For loading input files, don't use both positional arguments and the -i/--input flag");
+    std::vector<std::string> inputs = a.flag_inputs;
+    inputs.insert(inputs.end(), a.pos_inputs.begin(), a.pos_inputs.end());
+    std::vector<FILE *> files;
+    if (inputs.empty())
+        files.push_back(stdin);
+    for (auto &p : inputs)
+        files.push_back(open_input(p));
+    FILE *stream_fh = nullptr;
+    if (a.has_stream) {
+        if (inputs.size() != 1)
+            die_message("If you stream one file, you must also provide exactly one other file to be loaded");
+        stream_fh = a.stream == "-" ? stdin : open_input(a.stream);
+    }
+    uint8_t table[256];
+    encoding_array(table);
+    std::vector<Alignment> loaded;
+    for (size_t k = 0; k < files.size(); ++k) {  // load_fastas(): src/fastaio.rs:202-212
+        loaded.push_back(load_fasta(files[k], table));
+        if (k == 1 && loaded[0].width != loaded[1].width)
+            die_message(err_lengths(loaded[0].width, loaded[1].width));
+    }
+    Writer wr;
+    if (a.has_output) {
+        wr.fh = std::fopen(a.output.c_str(), "wb");
+        if (!wr.fh)
+            die_io(a.output, errno);
+    }
+    static char outbuf[1 << 20];
+    std::setvbuf(wr.fh, outbuf, _IOFBF, sizeof outbuf);
+    size_t threads = a.has_threads ? std::max<size_t>(a.threads, 1)  // src/lib.rs:253-263
+                                   : std::max<unsigned>(1, std::thread::hardware_concurrency());
+
+    const int measure = dst_measure_from_name(a.measure.c_str());
+    // ---- GPUs ----------------------------------------------------------------------------------
+    int ndev = 0;
+    if (dst_device_count(&ndev) != DST_OK || ndev == 0) {
+        std::fprintf(stderr, "Error: Gpu(\"no MI355X / HIP device visible: this build has no CPU path\")\n");
+        return 1;
+    }
+    const int G = std::max(1, std::min(a.gpus, ndev));
+    std::vector<Ctx> gpus(G);
+    for (int g = 0; g < G; ++g) {
+        if (dst_create(g, &gpus[g].h) != DST_OK) {
+            std::fprintf(stderr, "Error: Gpu(\"%s\")\n", dst_last_error(nullptr));
+            return 1;
+        }
+    }
+    for (int g = 0; g < G; ++g)
+        for (size_t k = 0; k < loaded.size(); ++k)
+            gpus[g].check(dst_upload(gpus[g].h, (int)k, loaded[k].codes.data(), loaded[k].n, loaded[k].width,
+                                     loaded[k].width, nullptr),
+                          "upload");
+    // tn93: per-record base counts by code (count_bases(), src/lib.rs:233-239), from the device
+    std::vector<std::vector<uint32_t>> counts(loaded.size());
+    if (measure == DST_TN93)
+        for (size_t k = 0; k < loaded.size(); ++k) {
+            counts[k].resize(loaded[k].n * 4);
+            gpus[0].check(dst_get_base_counts(gpus[0].h, (int)k, counts[k].data()), "base counts");
+        }
+
+    static const char header[] = "sequence1\tsequence2\tdistance\n";  // src/lib.rs:613
+    wr.write(header, sizeof header - 1);
+
+    Job job;
+    job.measure = measure;
+    job.fmt_threads = std::max<size_t>(1, threads / (size_t)G);
+    if (!stream_fh) {
+        // ---- load(): src/lib.rs:367-474 -------------------------------------------------------
+        job.square = loaded.size() == 1;
+        job.rows = &loaded[0];
+        job.cols = &loaded.back();
+        job.row_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
+        job.col_counts = measure == DST_TN93 ? counts.back().data() : nullptr;
+        run_slabs(gpus, job, 0, 1, a.slab_pairs, wr);
+    } else {
+        // ---- stream(): src/lib.rs:269-365; stream_fasta(): src/fastaio.rs:215-286 ---------------
+        const Alignment &ref = loaded[0];
+        cli::FastaReader reader(stream_fh);
+        cli::FastaRecord rec;
+        size_t record_counter = 0;
+        const size_t batch_records = std::max<size_t>(1, std::min<size_t>(4096, a.slab_pairs / std::max<size_t>(ref.n, 1)));
+        bool eof = false;
+        while (!eof) {
+            Alignment batch;
+            batch.width = ref.width;
+            while (batch.n < batch_records) {
+                const int rc = reader.next(rec);
+                if (rc < 0)
+                    die_message(reader.error());
+                if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty())) {
+                    eof = true;
+                    break;
+                }
+                record_counter += 1;
+                if (rec.seq.size() != ref.width)
+                    die_message(err_lengths(rec.seq.size(), ref.width));
+                encode_into(rec, table, batch, measure == DST_TN93);  // tn93: raw upper-case counts (:136-142)
+            }
+            if (batch.n == 0)
+                break;
+            for (int g = 0; g < G; ++g)
+                gpus[g].check(dst_upload(gpus[g].h, 1, batch.codes.data(), batch.n, batch.width, batch.width,
+                                         measure == DST_TN93 ? batch.counts.data() : nullptr),
+                              "upload batch");
+            Job sj = job;
+            sj.square = false;
+            sj.swap_ids = true;          // id1 = loaded record, id2 = streamed record (src/lib.rs:327-330)
+            sj.rows = &batch;            // streamed record outer ...
+            sj.cols = &ref;              // ... loaded record inner (src/lib.rs:323-324)
+            sj.row_counts = measure == DST_TN93 ? batch.counts.data() : nullptr;
+            sj.col_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
+            run_slabs(gpus, sj, 1, 0, a.slab_pairs, wr);
+        }
+        if (record_counter == 0)
+            die_message("Empty FASTA file");  // src/fastaio.rs:281-283
+    }
+    wr.flush();
+    for (auto &g : gpus)
+        dst_destroy(g.h);
+    return 0;
+}

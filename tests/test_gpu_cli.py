@@ -1,0 +1,139 @@
+"""GPU (-m gpu): the `distance` CLI end to end — TSV text identical to what the reference's
+gather_write would print for the oracle's distances (same header, order, `{}` / `{:.12}`)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import LETTERS, CODES, random_alignment
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "distance_amd", "cli", "distance")
+ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-C", os.path.dirname(CLI)], check=True)
+
+
+def to_text(codes, rng=None, lower_frac=0.0):
+    lut = {int(c): chr(LETTERS[k]) for k, c in enumerate(CODES)}
+    rows = []
+    for r in codes:
+        s = "".join(lut[int(c)] for c in r)
+        if rng is not None and lower_frac:
+            s = "".join(ch.lower() if rng.random() < lower_frac else ch for ch in s)
+        rows.append(s)
+    return rows
+
+
+def write_fasta(path, ids, seqs, width=0):
+    with open(path, "w") as fh:
+        for i, s in zip(ids, seqs):
+            fh.write(f">{i} some description\n")
+            if width:
+                for k in range(0, len(s), width):
+                    fh.write(s[k:k + width] + "\n")
+            else:
+                fh.write(s + "\n")
+
+
+def cli(args, stdin=None):
+    r = subprocess.run([CLI] + args, input=stdin, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout.decode()
+
+
+def expected_square(measure, ids, codes):
+    d = oracle.all_pairs_square(measure, codes)
+    ij = oracle.pairs_square(len(codes))
+    vals = [int(x) for x in d] if measure in oracle.INT_MEASURES else list(d)
+    return oracle.tsv(ids, ids, ij, vals)
+
+
+def test_golden_tsv_through_the_cli(tmp_path, golden):
+    for k, v in enumerate(golden["tsv"]):
+        a = tmp_path / f"a{k}.fasta"
+        write_fasta(a, [r[0] for r in v["loaded"]], [r[1] for r in v["loaded"]])
+        if v["mode"] == "square":
+            for extra in ([], ["-t", "2", "-b", "2"]):   # src/lib.rs:919-1002: output independent of -t/-b
+                assert cli(["-m", v["measure"], str(a)] + extra) == v["expected"]
+        else:
+            other = v.get("streamed") or v["second"]
+            b = tmp_path / f"b{k}.fasta"
+            write_fasta(b, [r[0] for r in other], [r[1] for r in other])
+            if v["mode"] == "stream":
+                assert cli(["-m", v["measure"], "-i", str(a), "-s", str(b)]) == v["expected"]
+                assert cli(["-m", v["measure"], str(a), "-s", "-"], stdin=b.read_bytes()) == v["expected"]
+            else:
+                assert cli(["-m", v["measure"], str(a), str(b)]) == v["expected"]
+                assert cli(["-m", v["measure"], "-i", str(a), str(b)]) == v["expected"]
+
+
+@pytest.mark.parametrize("measure", ALL)
+def test_square_matches_oracle_text(tmp_path, measure):
+    codes = random_alignment(57, 701, seed=3)
+    ids = [f"seq{i}" for i in range(len(codes))]
+    f = tmp_path / "a.fasta"
+    write_fasta(f, ids, to_text(codes), width=60)     # multi-line records
+    want = expected_square(measure, ids, codes)
+    assert cli(["-m", measure, str(f)]) == want
+    # slabs, formatting threads and -b never change the bytes
+    assert cli(["-m", measure, str(f), "--slab-pairs", "100", "-t", "3", "-b", "7"]) == want
+    out = tmp_path / "o.tsv"
+    assert cli(["-m", measure, "-i", str(f), "-o", str(out)]) == ""
+    assert out.read_text() == want
+    assert cli(["-m", measure], stdin=f.read_bytes()) == want      # stdin when no input is named
+
+
+def test_default_measure_is_raw(tmp_path):
+    codes = random_alignment(9, 100, seed=5)
+    ids = [f"s{i}" for i in range(9)]
+    f = tmp_path / "a.fasta"
+    write_fasta(f, ids, to_text(codes))
+    assert cli([str(f)]) == expected_square("raw", ids, codes)
+
+
+@pytest.mark.parametrize("measure", ALL)
+def test_two_files_and_stream_match_oracle_text(tmp_path, measure):
+    a = random_alignment(23, 333, seed=11)
+    b = random_alignment(31, 333, seed=12)
+    ida = [f"a{i}" for i in range(len(a))]
+    idb = [f"b{i}" for i in range(len(b))]
+    fa, fb = tmp_path / "a.fasta", tmp_path / "b.fasta"
+    rng = np.random.default_rng(1)
+    ta, tb = to_text(a), to_text(b, rng, lower_frac=0.3)     # lower case in the second file
+    write_fasta(fa, ida, ta)
+    write_fasta(fb, idb, tb)
+    ca = oracle.count_bases_matrix(a)
+    # two loaded files: counts by code for both (src/lib.rs:233-239)
+    d = oracle.all_pairs_rect(measure, a, b)
+    ij = [(i, j) for i in range(len(a)) for j in range(len(b))]
+    vals = [int(d[i, j]) if measure in oracle.INT_MEASURES else d[i, j] for i, j in ij]
+    assert cli(["-m", measure, str(fa), str(fb)]) == oracle.tsv(ida, idb, ij, vals)
+    # stream: streamed-record-major; streamed tn93 counts only upper-case characters
+    # (src/fastaio.rs:136-142)
+    cb = np.stack([oracle.encode_count_bases(s.encode())[1] for s in tb])
+    d = oracle.all_pairs_rect(measure, a, b, counts_a=ca, counts_b=cb) if measure == "tn93" else d
+    ij = [(i, j) for j in range(len(b)) for i in range(len(a))]
+    vals = [int(d[i, j]) if measure in oracle.INT_MEASURES else d[i, j] for i, j in ij]
+    want = oracle.tsv(ida, idb, ij, vals)
+    assert cli(["-m", measure, "-i", str(fa), "-s", str(fb)]) == want
+    assert cli(["-m", measure, "-i", str(fa), "-s", str(fb), "--slab-pairs", "50", "-b", "3"]) == want
+
+
+def test_special_float_text(tmp_path):
+    f = tmp_path / "a.fasta"
+    write_fasta(f, ["x", "y", "z", "n"], ["ACGTACGTACGTACGTAAAA", "ACGTACGTACGTACGTAAAA",
+                                           "CATGCATGCATGCATAAAAA", "NNNNNNNNNNNNNNNNNNNN"])
+    out = cli(["-m", "jc69", str(f)]).splitlines()
+    assert out[1] == "x\ty\t-0.000000000000"        # -0.75*ln(1): Rust prints the sign of -0.0
+    assert out[2] == "x\tz\tinf"                    # p = 0.75
+    assert out[3] == "x\tn\tNaN"                    # 0/0
+    out = cli(["-m", "tn93", str(f)]).splitlines()
+    assert out[1] == "x\ty\t0.000000000000"         # src/measures.rs:188-190 normalises -0.0
