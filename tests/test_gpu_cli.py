@@ -130,7 +130,7 @@ def test_two_files_and_stream_match_oracle_text(tmp_path, measure):
 def test_special_float_text(tmp_path):
     f = tmp_path / "a.fasta"
     write_fasta(f, ["x", "y", "z", "n"], ["ACGTACGTACGTACGTAAAA", "ACGTACGTACGTACGTAAAA",
-                                           "CATGCATGCATGCATAAAAA", "NNNNNNNNNNNNNNNNNNNN"])
+                                           "CATGCATGCATGCATTAAAA", "NNNNNNNNNNNNNNNNNNNN"])
     out = cli(["-m", "jc69", str(f)]).splitlines()
     assert out[1] == "x\ty\t-0.000000000000"        # -0.75*ln(1): Rust prints the sign of -0.0
     assert out[2] == "x\tz\tinf"                    # p = 0.75
