@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 import distance_amd as da
-from distance_amd.multi import gather_slabs, slab_layout
+from distance_amd.multi import chunked_layout, post_chunk, slab_layout
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
 HBM_COPY_GBS = 6290.0
@@ -116,9 +116,14 @@ def main():
     ap.add_argument("--len", type=int, default=0, help="override alignment width")
     ap.add_argument("--measure", default="", help="override measure")
     ap.add_argument("--variant", type=int, default=0, help="pair-kernel tile variant")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: sub-slabs per rank (send k overlaps compute k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements")
     ap.add_argument("--seed", type=int, default=0xD157A2CE)
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="debug: N ranks share GPU 0 and exchange over gloo via host staging (checks the "
+                         "multi-rank indexing on a 1-GPU box; RCCL itself needs one GPU per rank)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 re-computes sampled rows and compares")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,11 +136,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, L, measure = WORKLOADS[args.workload]
     n = args.n or n
@@ -150,22 +159,63 @@ def main():
     stream = work_stream.cuda_stream
     assert stream != 0
     codes = synth_alignment(n, L, args.seed, dev)      # every rank: the full replicated set
-    eng = da.Engine(local_rank)
+    eng = da.Engine(dev_index)
     eng.set_variant(args.variant)
 
     bounds, offsets = slab_layout(n, world, square=True)
     rb, re = bounds[rank], bounds[rank + 1]
     my_pairs = offsets[rank + 1] - offsets[rank]
     out_dtype = torch.int64 if measure in da.INT_MEASURES else torch.float64
-    local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
-    full_out = local_out if world == 1 else (
-        torch.empty(total_pairs, dtype=out_dtype, device=dev) if rank == 0 else None)
+    # N>1: each rank's range is cut into sub-slabs; sub-slab k is on its way to rank 0 (RCCL
+    # send/recv on RCCL's own stream) while sub-slab k+1 is being computed.
+    chunks = args.chunks if world > 1 else 1
+    sub_rows, sub_offs = chunked_layout(n, world, chunks)
+    if world == 1:
+        full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
+        local_out = full_out
+    elif rank == 0:
+        full_out = torch.empty(total_pairs, dtype=out_dtype, device=dev)
+        local_out = full_out[offsets[0]:offsets[1]]          # rank 0 computes straight into place
+    else:
+        full_out = None
+        local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+    base = offsets[rank]
+
+    staged = []
+
+    def rehearse_chunk(k):
+        # same indexing as post_chunk, but through pinned host tensors over gloo
+        torch.cuda.synchronize()
+        if rank == 0:
+            host = []
+            for r in range(1, world):
+                lo, hi = sub_offs[r][k], sub_offs[r][k + 1]
+                if hi > lo:
+                    t = torch.empty(hi - lo, dtype=out_dtype)
+                    staged.append(((lo, hi), t))
+                    host.append(dist.P2POp(dist.irecv, t, r))
+            return dist.batch_isend_irecv(host) if host else []
+        lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend, local_out[lo:hi].cpu(), 0)]) if hi > lo else []
 
     def step():
         eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
-        eng.run_square_device(measure, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
-        if world > 1:
-            gather_slabs(local_out, offsets, full_out, dst=0)
+        works = []
+        for k in range(chunks):
+            r0, r1 = sub_rows[rank][k], sub_rows[rank][k + 1]
+            lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
+            if hi > lo:
+                eng.run_square_device(measure, r0, r1, local_out.data_ptr() + 8 * lo, 8 * (hi - lo), stream=stream)
+            if world > 1 and not args.rehearse_gloo:
+                works += post_chunk(local_out, full_out, sub_offs, k, dst=0)
+            elif world > 1:
+                works += rehearse_chunk(k)
+        for w in works:
+            w.wait()
+        if world > 1 and args.rehearse_gloo and rank == 0:
+            for (lo, hi), t in staged:
+                full_out[lo:hi].copy_(t)
+            staged.clear()
 
     def fence():
         if world > 1:
@@ -197,10 +247,13 @@ def main():
         # roofline of the dominant kernel (pair_kernel): algorithmic bytes per launch = pairs of
         # the launch x (2L read + 8 written); duration = HIP events around the launch
         k_ms = float(np.mean(pair_ms))
-        algo_bytes = my_pairs * (2 * L + 8)
+        # the HIP events bracket the LAST pair-kernel launch of a step: the whole range at N=1,
+        # the last sub-slab at N>1
+        launch_pairs = sub_offs[rank][chunks] - sub_offs[rank][chunks - 1]
+        algo_bytes = launch_pairs * (2 * L + 8)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         words = (L + 127) // 128 * 4
-        lane_ops = my_pairs * words * OPS_PER_WORD[measure] / (k_ms * 1e-3)
+        lane_ops = launch_pairs * words * OPS_PER_WORD[measure] / (k_ms * 1e-3)
         result = {
             "metric": "pairwise comparisons/sec",
             "value": value,
@@ -217,7 +270,7 @@ def main():
             "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order"
                                    f"{', RCCL send/recv of slabs to rank 0' if world > 1 else ''})",
                        "name": args.workload, "n": n, "len": L, "measure": measure,
-                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count",
+                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f", {chunks} sub-slabs each, sends overlapped with compute" if world > 1 else ""),
                        "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -232,6 +285,20 @@ def main():
             "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms, "finalize": float(np.mean(fin_ms))},
             "site_compares_per_s": value * L,
         }
+        if args.verify:
+            check = da.Engine(dev_index)
+            check.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+            torch.cuda.synchronize()
+            bad = 0
+            probe = sorted(set([0, 1, n // 3, n // 2, n - 2] + [b for b in bounds[1:-1]] + [b - 1 for b in bounds[1:-1]]))
+            for row in [r for r in probe if 0 <= r < n - 1]:
+                want = check.run_square(measure, row, row + 1)
+                lo = da.square_row_start(n, row)
+                got = full_out[lo:lo + len(want)].cpu().numpy()
+                bad += int(not np.array_equal(got, want, equal_nan=True))
+            check.close()
+            result["verify"] = {"rows_checked": len(probe), "rows_bad": bad}
+            assert bad == 0, "multi-rank result differs from a single-engine run"
         if world == 1 and not args.no_cpu_baseline:
             rows = min(n, 4000)
             host = codes[:rows].cpu().numpy()

@@ -53,3 +53,52 @@ def gather_slabs(local: torch.Tensor, offsets: list[int], full: torch.Tensor | N
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return ops
+
+
+def chunked_layout(n: int, world: int, chunks: int):
+    """Every rank's row range cut again into `chunks` sub-ranges of near-equal pair count, so a
+    rank can send sub-slab k while it computes sub-slab k+1.
+
+    Returns (row_bounds, pair_offsets): row_bounds[r][k] .. row_bounds[r][k+1] are the rows of
+    rank r's k-th sub-slab and pair_offsets[r][k] its first canonical pair index."""
+    bounds, _ = slab_layout(n, world, square=True)
+    row_bounds, pair_offsets = [], []
+    for r in range(world):
+        lo, hi = square_row_start(n, bounds[r]), square_row_start(n, bounds[r + 1])
+        rows = [bounds[r]]
+        for k in range(1, chunks):
+            target = lo + (hi - lo) * k // chunks
+            a, b = rows[-1], bounds[r + 1]
+            while a < b:                      # first row whose start index reaches the target
+                mid = (a + b) // 2
+                if square_row_start(n, mid) < target:
+                    a = mid + 1
+                else:
+                    b = mid
+            rows.append(a)
+        rows.append(bounds[r + 1])
+        row_bounds.append(rows)
+        pair_offsets.append([square_row_start(n, x) for x in rows])
+    return row_bounds, pair_offsets
+
+
+def post_chunk(local: torch.Tensor | None, full: torch.Tensor | None, pair_offsets, k: int,
+               dst: int = 0, group=None):
+    """Post (do not wait for) the exchange of sub-slab k: every rank != dst sends
+    local[its chunk-k range, relative to its slab start]; dst receives each straight into `full`.
+    On nccl the transfers run on RCCL's stream, ordered after the work already queued on the
+    current stream, so the caller can go on computing sub-slab k+1.  Returns work handles."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            lo, hi = pair_offsets[r][k], pair_offsets[r][k + 1]
+            if r != dst and hi > lo:
+                ops.append(dist.P2POp(dist.irecv, full[lo:hi], r, group))
+    else:
+        base = pair_offsets[rank][0]
+        lo, hi = pair_offsets[rank][k] - base, pair_offsets[rank][k + 1] - base
+        if hi > lo:
+            ops.append(dist.P2POp(dist.isend, local[lo:hi], dst, group))
+    return dist.batch_isend_irecv(ops) if ops else []

@@ -59,3 +59,58 @@ def test_slab_layout_rect_and_square():
     assert all(x <= y for x, y in zip(o, o[1:]))
     b, o = slab_layout(10, 4, square=False, n_cols=7)
     assert o == [x * 7 for x in b] and o[-1] == 70
+
+
+def _worker_chunked(rank, world, port, n, L, chunks, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from distance_amd.multi import chunked_layout, post_chunk
+    from helpers import random_alignment
+
+    codes = random_alignment(n, L, seed=321)
+    rows, offs = chunked_layout(n, world, chunks)
+    total = n * (n - 1) // 2
+    full = torch.full((total,), -7.0, dtype=torch.float64) if rank == 0 else None
+    base = offs[rank][0]
+    local = full[offs[0][0]:offs[0][-1]] if rank == 0 else torch.empty(offs[rank][-1] - base, dtype=torch.float64)
+    works = []
+    for step in range(2):                     # two steps: buffers are reused, like bench.py
+        for k in range(chunks):
+            lo, hi = offs[rank][k], offs[rank][k + 1]
+            part = oracle.all_pairs_square("jc69", codes, pair_range=(lo, hi))
+            local[lo - base:hi - base] = torch.from_numpy(part)
+            works += post_chunk(local, full, offs, k, dst=0)
+        for w in works:
+            w.wait()
+        works = []
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,chunks", [(2, 37, 3), (3, 20, 4), (2, 3, 4)])
+def test_chunked_overlap_exchange_reassembles_canonical_order(tmp_path, world, n, chunks):
+    import oracle
+    from helpers import random_alignment
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker_chunked, args=(world, _free_port(), n, 90, chunks, out), nprocs=world, join=True)
+    want = oracle.all_pairs_square("jc69", random_alignment(n, 90, seed=321))
+    assert np.array_equal(np.load(out), want, equal_nan=True)
+
+
+def test_chunked_layout_is_a_refinement_of_the_rank_partition():
+    from distance_amd.multi import chunked_layout, slab_layout
+    n, world, chunks = 5000, 8, 4
+    rows, offs = chunked_layout(n, world, chunks)
+    bounds, offsets = slab_layout(n, world)
+    for r in range(world):
+        assert rows[r][0] == bounds[r] and rows[r][-1] == bounds[r + 1]
+        assert offs[r][0] == offsets[r] and offs[r][-1] == offsets[r + 1]
+        assert all(a <= b for a, b in zip(rows[r], rows[r][1:]))
+        sizes = [offs[r][k + 1] - offs[r][k] for k in range(chunks)]
+        assert max(sizes) - min(sizes) <= 2 * n
