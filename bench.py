@@ -14,6 +14,7 @@ Default workload: 50,000 x 30,000, -m raw — the shape the north-star target is
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -84,7 +85,9 @@ def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 1
     """The oracle (restated reference algorithm, C, pthreads) timed on this box's host cores on a
     bounded sample of the same workload: the leading pairs of the canonical order."""
     import oracle
-    cores = os.cpu_count() or 1
+    # the GPU box grants a CPU share of 16 threads per GPU: size the pool to that, not to the host
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("DST_BENCH_THREADS", min(avail, 16)))
     try:
         oracle.build(native=True)
         native = True
@@ -104,6 +107,21 @@ def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 1
             "sample": f"first {sample} canonical pairs of the same alignment ({n} x {codes_host.shape[1]} "
                       f"host slice), -m {measure}, {dt:.1f} s, oracle/distance_oracle.c "
                       f"({'-O3 -march=native' if native else '-O2'}), {cores} threads"}
+
+
+def measured_traffic(name: str, variant: int):
+    """HBM bytes per pair-kernel launch from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
+    FETCH_SIZE x 1024 x 2 (gfx950 under-count of 16-B/lane streaming reads, MI355X_MICROARCH.md §HBM)
+    + WRITE_SIZE x 1024), or None when this workload/variant was not profiled."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            for rec in json.load(open(path)):
+                if rec["workload"] == name and rec["variant"] == variant and rec["kernel"] == "pair_kernel":
+                    best = rec
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -253,6 +271,7 @@ def main():
         algo_bytes = launch_pairs * (2 * L + 8)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         words = (L + 127) // 128 * 4
+        traffic = measured_traffic(args.workload if not (args.n or args.len or args.measure) else "", args.variant)
         lane_ops = launch_pairs * words * OPS_PER_WORD[measure] / (k_ms * 1e-3)
         result = {
             "metric": "pairwise comparisons/sec",
@@ -273,7 +292,9 @@ def main():
                        "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f", {chunks} sub-slabs each, sends overlapped with compute" if world > 1 else ""),
                        "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic["hbm_bytes_per_launch"] if traffic and world == 1 else None),
+                         "traffic_source": (traffic["source"] if traffic and world == 1 else None),
                          "kernel": "pair_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,

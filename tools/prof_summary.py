@@ -62,6 +62,31 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
                          f"lds={m[3]} scratch={m[4]} grid={m[5]} wg={m[6]}")
             for c, vals in acc[s].items():
                 lines.append(f"    {c:28s} {sum(vals)/len(vals):18.3f}")
+# per-launch HBM traffic of the engine's kernels -> traffic.json (read by bench.py)
+traffic = []
+for tag, wl in (("pmc", "C2"), ("pmcdef", "C3raw")):
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for path in glob.glob(os.path.join(src, f"{tag}_{c}", "*", "*_counter_collection.csv")):
+            per = defaultdict(list)
+            for r in csv.DictReader(open(path)):
+                s = short(r["Kernel_Name"])
+                if s and r["Counter_Name"] == c:
+                    per[s].append(float(r["Counter_Value"]))
+            for s, v in per.items():
+                vals.setdefault(s, {})[c] = sum(v) / len(v)
+    for s, v in vals.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            traffic.append({"workload": wl, "variant": 0, "kernel": s.split("<")[0], "kernel_full": s,
+                            "FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
+                            "hbm_bytes_per_launch": v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024,
+                            "source": f"{os.path.basename(out.rstrip('/'))}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                      "separate passes, mean per launch; FETCH_SIZE x2 (gfx950 16-B/lane "
+                                      "streaming-read under-count), KiB -> bytes"})
+if traffic:
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    lines.append("# HBM traffic per launch (traffic.json): " + "; ".join(
+        f"{t['workload']} {t['kernel_full']}: {t['hbm_bytes_per_launch']/1e9:.3f} GB" for t in traffic))
 lines.append("")
 for path in sorted(glob.glob(os.path.join(src, "*_bench.json"))):
     try:

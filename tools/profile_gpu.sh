@@ -13,6 +13,9 @@ echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- $BENCH --workload C2 > "$OUT/pmc_${C}_bench.json" 2> "$OUT/pmc_$C.err"
   echo "pmc $C rc=$?"
+  # the default workload too: its per-launch HBM traffic is what bench.py reports as roofline.traffic
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmcdef_$C" -- $BENCH > "$OUT/pmcdef_${C}_bench.json" 2> "$OUT/pmcdef_$C.err"
+  echo "pmcdef $C rc=$?"
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_SQ" -- $BENCH --workload C2 > "$OUT/pmc_SQ_bench.json" 2> "$OUT/pmc_SQ.err"
 echo "pmc SQ rc=$?"
