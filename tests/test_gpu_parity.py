@@ -303,3 +303,44 @@ def test_large_shape_properties(eng):
     for j in (101, 999, 2999):
         want = oracle.pair_distance("tn93", codes[100], codes[j], q_counts=counts[0])
         assert abs(tn[da.square_row_start(n, 100) + j - 101 - p0] - want) <= TOL
+
+
+def test_very_long_alignment_rect_and_stream(eng):
+    """C4-shaped: few records x millions of sites (39k+ chunks, tallies in the millions)."""
+    L = 2_000_003
+    a = random_alignment(6, L, 91, p_ambig=1e-3, p_gap=1e-2, divergence=0.05)
+    b = random_alignment(5, L, 92, p_ambig=1e-3, p_gap=1e-2, divergence=0.05)
+    b[:, :1000] = a[0, :1000]            # shared prefix: both-known runs
+    eng.upload(0, a)
+    want = oracle.all_pairs_rect("n_high", a, b)
+    got = eng.run_stream_batch("n_high", b)
+    assert np.array_equal(got, want.T.astype(np.int64))
+    assert int(got.max()) > 65535        # tallies beyond 16 bits
+    tl = eng.run_rect("tn93", row_slot=0, col_slot=1, tallies=True)
+    for i in range(6):
+        for j in range(5):
+            assert list(tl[i, j]) == list(oracle.tallies("tn93", a[i], b[j]))
+    assert_close(eng.run_square("raw"), oracle.all_pairs_square("raw", a))
+
+
+def test_many_records_short_alignment(eng):
+    """C5-shaped: many records x short alignment; rows cross several scratch slabs."""
+    n, L = 6000, 200
+    codes = random_alignment(n, L, 93, divergence=0.1)
+    eng.upload(0, codes)
+    eng.set_scratch_limit(32 << 20)      # ~4M pairs per slab -> 5 slabs
+    try:
+        jc = eng.run_square("jc69")
+    finally:
+        eng.set_scratch_limit(32 << 30)
+    tl = eng.run_square("jc69", tallies=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = tl[:, 0] / tl[:, 1].astype(np.float64)
+        want = -0.75 * np.log(1.0 - (4.0 / 3.0) * p)
+    assert_close(jc, want)
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        i = int(rng.integers(0, n - 1))
+        j = int(rng.integers(i + 1, n))
+        at = da.square_row_start(n, i) + j - i - 1
+        assert list(tl[at]) == list(oracle.tallies("raw", codes[i], codes[j]))
