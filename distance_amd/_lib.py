@@ -42,7 +42,6 @@ _SIGS = {
     "dst_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "dst_destroy": (C.c_int, [_vp]),
     "dst_last_error": (C.c_char_p, [_vp]),
-    "dst_set_scratch_limit": (C.c_int, [_vp, C.c_size_t]),
     "dst_set_variant": (C.c_int, [_vp, C.c_int]),
     "dst_variant_count": (C.c_int, [C.c_int]),
     "dst_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),

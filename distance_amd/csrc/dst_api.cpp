@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "dst_internal.h"
 
@@ -19,23 +20,22 @@ struct dst_ctx {
     uint8_t *stage = nullptr;
     size_t stage_bytes = 0;
     unsigned long long *d_first_bad = nullptr;
-    // tally scratch of the two-pass (tally -> finalize) float path
-    uint32_t *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    size_t scratch_limit = (size_t)32 << 30;
-    // tile list cache
-    BlockDesc *d_blocks = nullptr;
-    size_t blocks_cap = 0;
-    struct {
-        bool valid = false, square = false;
+    // tile schedules already on the device, keyed by the launch geometry (multi-GPU runs cycle
+    // through a few sub-slab ranges every step: no host sync or H2D on a hit)
+    struct Schedule {
+        bool square = false;
         uint64_t rb = 0, re = 0, ncols = 0;
         int bm = 0, bn = 0;
         uint32_t nblocks = 0;
-    } bkey;
+        BlockDesc *d_blocks = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::vector<Schedule> schedules;
+    uint64_t schedule_clock = 0;
     int variant = 0;
-    hipEvent_t ev[6] = {};
-    float pair_ms = 0, fin_ms = 0, pack_ms = 0;
-    bool timed_pair = false, timed_fin = false, timed_pack = false;
+    hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
+    float pair_ms = 0, pack_ms = 0;
+    bool timed_pair = false, timed_pack = false;
     std::string err;
 };
 
@@ -116,9 +116,9 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     if (rc)
         return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_bad, 0xFF, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
     HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, ctx->d_first_bad, stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->timed_pack = true;
     if (d_counts) {
         HIP_TRY(ctx, hipMemsetAsync(s.counts, 0, s.npad * 4 * sizeof(uint32_t), stream));
@@ -138,7 +138,6 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
         return fail(ctx, DST_ERR_INVALID_CODE, msg);
     }
     s.loaded = true;
-    ctx->bkey.valid = false;
     return DST_OK;
 }
 
@@ -152,40 +151,47 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 }
 
 int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t ncols, TileShape ts,
-                   hipStream_t stream, uint32_t *nblocks)
+                   hipStream_t stream, const BlockDesc **d_blocks, uint32_t *nblocks)
 {
-    auto &k = ctx->bkey;
-    if (k.valid && k.square == square && k.rb == rb && k.re == re && k.ncols == ncols &&
-        k.bm == ts.bm && k.bn == ts.bn) {
-        *nblocks = k.nblocks;
-        return DST_OK;
+    constexpr size_t kMaxSchedules = 16;
+    for (auto &s : ctx->schedules) {
+        if (s.square == square && s.rb == rb && s.re == re && s.ncols == ncols && s.bm == ts.bm && s.bn == ts.bn) {
+            s.last_use = ++ctx->schedule_clock;
+            *d_blocks = s.d_blocks;
+            *nblocks = s.nblocks;
+            return DST_OK;
+        }
     }
     std::vector<BlockDesc> blocks = build_blocks(square, rb, re, ncols, ts);
-    const size_t bytes = blocks.size() * sizeof(BlockDesc);
-    if (bytes > ctx->blocks_cap) {
-        // the previous list may still be read by an in-flight kernel on this stream
+    dst_ctx::Schedule s;
+    s.square = square;
+    s.rb = rb;
+    s.re = re;
+    s.ncols = ncols;
+    s.bm = ts.bm;
+    s.bn = ts.bn;
+    s.nblocks = (uint32_t)blocks.size();
+    s.last_use = ++ctx->schedule_clock;
+    if (ctx->schedules.size() >= kMaxSchedules) {
+        // evict the least recently used; an in-flight kernel may still read it
         HIP_TRY(ctx, hipStreamSynchronize(stream));
-        if (ctx->d_blocks)
-            HIP_TRY(ctx, hipFree(ctx->d_blocks));
-        ctx->d_blocks = nullptr;
-        ctx->blocks_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, bytes));
-        ctx->blocks_cap = bytes;
+        size_t victim = 0;
+        for (size_t k = 1; k < ctx->schedules.size(); ++k)
+            if (ctx->schedules[k].last_use < ctx->schedules[victim].last_use)
+                victim = k;
+        if (ctx->schedules[victim].d_blocks)
+            HIP_TRY(ctx, hipFree(ctx->schedules[victim].d_blocks));
+        ctx->schedules.erase(ctx->schedules.begin() + (long)victim);
     }
-    if (bytes) {
-        // synchronous copy from pageable memory; ordered after prior work on `stream`
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_blocks, blocks.data(), bytes, hipMemcpyHostToDevice));
+    if (!blocks.empty()) {
+        const size_t bytes = blocks.size() * sizeof(BlockDesc);
+        HIP_TRY(ctx, hipMalloc((void **)&s.d_blocks, bytes));
+        // pageable source: the copy is complete on return, later kernels on any stream see it
+        HIP_TRY(ctx, hipMemcpy(s.d_blocks, blocks.data(), bytes, hipMemcpyHostToDevice));
     }
-    k.valid = true;
-    k.square = square;
-    k.rb = rb;
-    k.re = re;
-    k.ncols = ncols;
-    k.bm = ts.bm;
-    k.bn = ts.bn;
-    k.nblocks = (uint32_t)blocks.size();
-    *nblocks = k.nblocks;
+    ctx->schedules.push_back(s);
+    *d_blocks = s.d_blocks;
+    *nblocks = s.nblocks;
     return DST_OK;
 }
 
@@ -219,15 +225,13 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
     const size_t need = dst_out_bytes(measure, out_kind, total_pairs);
     if (need > cap)
         return fail(ctx, DST_ERR_CAPACITY, "output buffer too small for the requested rows");
-    ctx->timed_pair = ctx->timed_fin = false;
-    ctx->pair_ms = ctx->fin_ms = 0;
+    ctx->timed_pair = false;
+    ctx->pair_ms = 0;
     if (total_pairs == 0)
         return DST_OK;
     if (!d_out)
         return fail(ctx, DST_ERR_ARG, "null output pointer");
 
-    const int width = tally_width(measure);
-    const bool direct = out_kind == DST_OUT_TALLY || measure_is_int(measure);
     if (measure == DST_TN93 && out_kind == DST_OUT_DISTANCE) {
         int rc = need_counts(ctx, rows, stream);
         if (!rc && &cols != &rows)
@@ -236,74 +240,27 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
             return rc;
     }
     const TileShape ts = tile_shape(measure, ctx->variant);
-    const uint64_t out_base = square ? square_row_start(cols.n, rb) : 0;
-
-    // float distances go tally -> scratch -> finalize; cut rows into slabs whose tallies fit
-    uint64_t max_pairs = ~0ull;
-    if (!direct) {
-        const size_t per_pair = (size_t)width * sizeof(uint32_t);
-        const size_t want = std::min((size_t)total_pairs * per_pair, ctx->scratch_limit);
-        size_t have = ctx->scratch_bytes;
-        if (have < want) {
-            HIP_TRY(ctx, hipStreamSynchronize(stream));
-            int rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes, want);
-            if (rc)
-                return rc;
-        }
-        max_pairs = std::max<uint64_t>(ctx->scratch_bytes / per_pair, 1);
-    }
-
-    bool first = true;
-    for (uint64_t sb = rb; sb < re;) {
-        const uint64_t se = slab_end(square, cols.n, sb, re, max_pairs);
-        const uint64_t slab_pairs = pairs_in_rows(square, cols.n, sb, se);
-        if (!direct && slab_pairs * width * sizeof(uint32_t) > ctx->scratch_bytes) {
-            // one row alone exceeds the scratch: grow it (rows are the slab granule)
-            HIP_TRY(ctx, hipStreamSynchronize(stream));
-            int rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes,
-                                  (size_t)slab_pairs * width * sizeof(uint32_t));
-            if (rc)
-                return rc;
-        }
-        uint32_t nblocks = 0;
-        int rc = prepare_blocks(ctx, square, sb, se, cols.n, ts, stream, &nblocks);
-        if (rc)
-            return rc;
-        const uint64_t slab_base = square ? square_row_start(cols.n, sb) : (sb - rb) * cols.n;
-        const uint64_t slab_off = square ? slab_base - out_base : slab_base;  // pairs before the slab
-        PairLaunch pl{};
-        pl.rows = &rows;
-        pl.cols = &cols;
-        pl.square = square;
-        pl.row_begin = sb;
-        pl.row_end = se;
-        pl.out_base = square ? slab_base : 0;
-        pl.d_blocks = ctx->d_blocks;
-        pl.nblocks = nblocks;
-        if (direct) {
-            if (out_kind == DST_OUT_TALLY)
-                pl.d_tallies = (uint32_t *)d_out + slab_off * width;
-            else
-                pl.d_int_out = (int64_t *)d_out + slab_off;
-        } else {
-            pl.d_tallies = ctx->scratch;
-        }
-        if (nblocks) {
-            if (first)
-                HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-            HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-            ctx->timed_pair = true;
-            if (!direct) {
-                if (first)
-                    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-                HIP_TRY(ctx, launch_finalize(measure, pl, (double *)d_out + slab_off, stream));
-                HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-                ctx->timed_fin = true;
-            }
-            first = false;
-        }
-        sb = se;
+    uint32_t nblocks = 0;
+    const BlockDesc *d_blocks = nullptr;
+    int rc = prepare_blocks(ctx, square, rb, re, cols.n, ts, stream, &d_blocks, &nblocks);
+    if (rc)
+        return rc;
+    PairLaunch pl{};
+    pl.rows = &rows;
+    pl.cols = &cols;
+    pl.square = square;
+    pl.row_begin = rb;
+    pl.row_end = re;
+    pl.out_base = square ? square_row_start(cols.n, rb) : 0;
+    pl.out_kind = out_kind;
+    pl.d_out = d_out;
+    pl.d_blocks = d_blocks;
+    pl.nblocks = nblocks;
+    if (nblocks) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+        HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+        ctx->timed_pair = true;
     }
     if (!stream_v)
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -413,10 +370,9 @@ int dst_destroy(dst_ctx *ctx)
     free_set(ctx->set[1]);
     if (ctx->stage)
         (void)hipFree(ctx->stage);
-    if (ctx->scratch)
-        (void)hipFree(ctx->scratch);
-    if (ctx->d_blocks)
-        (void)hipFree(ctx->d_blocks);
+    for (auto &s : ctx->schedules)
+        if (s.d_blocks)
+            (void)hipFree(s.d_blocks);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
     for (auto &ev : ctx->ev)
@@ -428,21 +384,6 @@ int dst_destroy(dst_ctx *ctx)
     return DST_OK;
 }
 
-int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes)
-{
-    if (!ctx || bytes < 1024)
-        return DST_ERR_ARG;
-    ctx->scratch_limit = bytes;
-    if (ctx->scratch_bytes > bytes) {  // shrink now so the new limit is what runs see
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        HIP_TRY(ctx, hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-    }
-    return DST_OK;
-}
-
 int dst_variant_count(int measure) { return variant_count(measure); }
 
 int dst_set_variant(dst_ctx *ctx, int variant)
@@ -450,7 +391,6 @@ int dst_set_variant(dst_ctx *ctx, int variant)
     if (!ctx || variant < 0)
         return DST_ERR_ARG;
     ctx->variant = variant;
-    ctx->bkey.valid = false;
     return DST_OK;
 }
 
@@ -591,18 +531,14 @@ int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ctx->pair_ms, ctx->ev[0], ctx->ev[1]));
     }
-    if (ctx->timed_fin) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ctx->fin_ms, ctx->ev[2], ctx->ev[3]));
-    }
     if (ctx->timed_pack) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pack_ms, ctx->ev[4], ctx->ev[5]));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pack_ms, ctx->ev[2], ctx->ev[3]));
     }
     if (pair_ms)
         *pair_ms = ctx->pair_ms;
     if (finalize_ms)
-        *finalize_ms = ctx->fin_ms;
+        *finalize_ms = 0.0f;  // finalisation is fused into the pair kernel's epilogue
     if (pack_ms)
         *pack_ms = ctx->pack_ms;
     return DST_OK;

@@ -41,22 +41,6 @@ uint64_t pairs_in_rows(bool square, uint64_t n_cols, uint64_t row_begin, uint64_
     return square_row_start(n_cols, e) - square_row_start(n_cols, b);
 }
 
-uint64_t slab_end(bool square, uint64_t n_cols, uint64_t row_begin, uint64_t row_end,
-                  uint64_t max_pairs)
-{
-    if (pairs_in_rows(square, n_cols, row_begin, row_end) <= max_pairs)
-        return row_end;
-    uint64_t lo = row_begin + 1, hi = row_end;  // invariant: rows [row_begin, lo) always accepted
-    while (lo < hi) {
-        const uint64_t mid = lo + (hi - lo + 1) / 2;
-        if (pairs_in_rows(square, n_cols, row_begin, mid) <= max_pairs)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    return lo;
-}
-
 // Tiles of one launch.  A column tile ("panel") of BN records is shared by every row tile that
 // meets it; the panel is the big operand (BN >> BM), so all row tiles of one panel are queued
 // back to back on ONE of 8 queues, and the queues are interleaved so that block ids b, b+8, ...

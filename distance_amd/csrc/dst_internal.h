@@ -61,8 +61,8 @@ struct PairLaunch {
     bool square;
     uint64_t row_begin, row_end;  // rows of `rows` this launch covers
     uint64_t out_base;            // canonical index of the first pair of this launch
-    uint32_t *d_tallies;          // NC uint32 per pair (scratch or the caller's buffer)
-    int64_t *d_int_out;           // n / n_high distance output (fused), or nullptr
+    int out_kind;                 // DST_OUT_DISTANCE (f64 / int64 by measure) or DST_OUT_TALLY
+    void *d_out;                  // first pair of this launch
     const BlockDesc *d_blocks;
     uint32_t nblocks;
 };
@@ -72,7 +72,6 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
                        unsigned long long *d_first_bad, hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
-hipError_t launch_finalize(int measure, const PairLaunch &pl, double *d_out, hipStream_t stream);
 TileShape tile_shape(int measure, int variant);
 int variant_count(int measure);
 
@@ -85,8 +84,5 @@ std::vector<BlockDesc> build_blocks(bool square, uint64_t row_begin, uint64_t ro
                                     uint64_t n_cols, TileShape ts);
 uint64_t square_row_start(uint64_t n, uint64_t i);
 uint64_t pairs_in_rows(bool square, uint64_t n_cols, uint64_t row_begin, uint64_t row_end);
-// largest row_end' <= row_end such that rows [row_begin,row_end') hold <= max_pairs (>= 1 row)
-uint64_t slab_end(bool square, uint64_t n_cols, uint64_t row_begin, uint64_t row_end,
-                  uint64_t max_pairs);
 
 }  // namespace dst

@@ -4,9 +4,8 @@
 //   counts_kernel    per-record {A,T,G,C} counts            (src/fastaio.rs:53-66)
 //   pair_kernel<M>   site tallies of every pair of a tile   (src/measures.rs:14-23, 56-66,
 //                                                            85-107, 156-175)
-//   finalize_kernel  tallies -> f64 distance, reference operation order
-//                                                           (src/measures.rs:68, 76, 109-112,
-//                                                            118-190)
+//                    and, fused in its epilogue, tallies -> f64 distance in the reference's
+//                    operation order              (src/measures.rs:68, 76, 109-112, 118-190)
 //
 // Design (DESIGN.md has the numbers): integer / bitwise work, no MFMA.  One pair costs 5..10
 // VALU ops per 32 sites.  A block owns BM "row" records x 256*TN "column" records.  Each lane
@@ -278,6 +277,72 @@ __device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
 // =============================================================================================
 // pair kernel
 // =============================================================================================
+// =============================================================================================
+// finalisation math: tallies -> f64 in the reference's operation order (fused into the pair
+// kernel's epilogue).  The build passes -ffp-contract=off: rustc never fuses a*b+c.
+// =============================================================================================
+// (the build passes -ffp-contract=off for the whole file)
+__device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
+{
+    return (double)n / (double)d;
+}
+
+__device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d)  // src/measures.rs:72-77
+{
+    const double p = fin_raw(n, d);
+    return -0.75 * log(1.0 - (4.0 / 3.0) * p);
+}
+
+__device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv)  // :109-112
+{
+    const double P = (double)ts / (double)count_L;
+    const double Q = (double)tv / (double)count_L;
+    return -0.5 * log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
+}
+
+// counts = {A, T, G, C}; sums keep the reference's operand order (target first), :118-190
+__device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
+                                           uint32_t count_P2, uint4 qc, uint4 tc)
+{
+    const uint64_t L = (uint64_t)qc.x + qc.y + qc.z + qc.w + tc.x + tc.y + tc.z + tc.w;
+    const double g_A = ((double)tc.x + (double)qc.x) / (double)L;
+    const double g_C = ((double)tc.w + (double)qc.w) / (double)L;
+    const double g_G = ((double)tc.z + (double)qc.z) / (double)L;
+    const double g_T = ((double)tc.y + (double)qc.y) / (double)L;
+    const double g_R = ((double)tc.x + (double)qc.x + (double)tc.z + (double)qc.z) / (double)L;
+    const double g_Y = ((double)tc.w + (double)qc.w + (double)tc.y + (double)qc.y) / (double)L;
+    const double k1 = 2.0 * g_A * g_G / g_R;
+    const double k2 = 2.0 * g_T * g_C / g_Y;
+    const double k3 = 2.0 * (g_R * g_Y - g_A * g_G * g_Y / g_R - g_T * g_C * g_R / g_Y);
+    const double P1 = (double)count_P1 / (double)count_L;
+    const double P2 = (double)count_P2 / (double)count_L;
+    const double Q = (double)(count_d - (count_P1 + count_P2)) / (double)count_L;
+    const double w1 = 1.0 - P1 / k1 - Q / (2.0 * g_R);
+    const double w2 = 1.0 - P2 / k2 - Q / (2.0 * g_Y);
+    const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
+    double d = -k1 * log(w1) - k2 * log(w2) - k3 * log(w3);
+    if (d == 0.0)
+        d = 0.0;
+    return d;
+}
+
+constexpr int OUT_TALLY = -1;  // uint32 x NT site tallies per pair
+constexpr int OUT_INT = -2;    // int64 (n / n_high)
+// OUT >= 0: the measure id whose f64 distance the epilogue writes
+
+template <int MEASURE>
+__device__ __forceinline__ double finalize_pair(const uint32_t *o, uint4 qc, uint4 tc)
+{
+    if constexpr (MEASURE == DST_RAW)
+        return fin_raw(o[0], o[1]);
+    else if constexpr (MEASURE == DST_JC69)
+        return fin_jc69(o[0], o[1]);
+    else if constexpr (MEASURE == DST_K80)
+        return fin_k80(o[0], o[1], o[2]);
+    else
+        return fin_tn93(o[0], o[1], o[2], o[3], qc, tc);
+}
+
 // One block = BM row records x 256*TN column records, 256 threads (4 waves), MINW blocks per CU
 // (MINW = waves per SIMD asked of the register allocator).
 // Per 128-site chunk:
@@ -287,17 +352,26 @@ __device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
 //            barrier per chunk; every lane reads the same 16 bytes (broadcast ds_read_b128), so
 //            LDS time is 4 cycles per plane per row per wave against 64*TN VALU cycles;
 //   tallies: BM*TN*NC accumulators live in VGPRs for the whole sweep over L.
-template <class M, int BM, int TN, int MINW, bool INT_OUT>
+//   epilogue: tallies (OUT_TALLY), int64 (OUT_INT) or — for the f64 measures — the finalisation
+//            itself: the lane's tallies go through a lane-private LDS slot so that ONE copy of the
+//            (log-heavy) finalisation code runs in a rolled loop instead of BM*TN inlined copies;
+//            no tally round trip through HBM, no second kernel.
+template <class M, int BM, int TN, int MINW, int OUT>
 __global__ __launch_bounds__(256, MINW) void pair_kernel(
     const uint4 *__restrict__ qpl, const uint4 *__restrict__ tpl,
-    const BlockDesc *__restrict__ blocks, uint32_t *__restrict__ tallies,
-    int64_t *__restrict__ int_out, uint32_t nchunks, uint32_t q_npad, uint32_t t_npad,
-    uint32_t n_cols, uint32_t row_begin, uint32_t row_end, uint64_t out_base, int square)
+    const BlockDesc *__restrict__ blocks, void *__restrict__ out_v,
+    const uint32_t *__restrict__ q_counts, const uint32_t *__restrict__ t_counts, uint32_t nchunks,
+    uint32_t q_npad, uint32_t t_npad, uint32_t n_cols, uint32_t row_begin, uint32_t row_end,
+    uint64_t out_base, int square)
 {
-    constexpr int NP = M::NP, NC = M::NC;
+    constexpr int NP = M::NP, NC = M::NC, NT = M::NT;
     constexpr int QV = NP * BM;               // uint4 per staged row tile
     constexpr int QL = (QV + 255) / 256;      // staging loads per thread
-    __shared__ uint4 qs[2][NP][BM];
+    constexpr int RP = (BM % 2 == 0) ? BM / 2 : BM;   // rows per epilogue pass
+    constexpr int STAGE_U4 = OUT >= 0 ? RP * TN * NT * 256 / 4 : 0;
+    constexpr int SMEM_U4 = (2 * QV > STAGE_U4) ? 2 * QV : STAGE_U4;
+    __shared__ uint4 smem[SMEM_U4];
+    uint4 (*qs)[NP][BM] = reinterpret_cast<uint4 (*)[NP][BM]>(smem);
 
     const uint32_t i0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].i0);
     const uint32_t j0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].j0);
@@ -386,113 +460,72 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     }
 
     const uint32_t total = nchunks * kChunkSites;  // padded sites are N on both sides: "share"
+    if constexpr (OUT < 0) {
 #pragma unroll
-    for (int r = 0; r < BM; ++r) {
-        const uint32_t i = i0 + r;
-        if (i >= row_end)
-            break;
-        const uint64_t row_at = square ? (tri_row_start(n_cols, i) - out_base) - (uint64_t)(i + 1)
-                                       : (uint64_t)(i - row_begin) * n_cols;
+        for (int r = 0; r < BM; ++r) {
+            const uint32_t i = i0 + r;
+            if (i >= row_end)
+                break;
+            const uint64_t row_at = square ? (tri_row_start(n_cols, i) - out_base) - (uint64_t)(i + 1)
+                                           : (uint64_t)(i - row_begin) * n_cols;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const uint32_t j = j0 + 256 * tn + threadIdx.x;
-            if (j < n_cols && (!square || j > i)) {
-                const uint64_t at = row_at + j;
-                uint32_t o[M::NT];
-                M::tallies(acc[r][tn], total, o);
-                if constexpr (INT_OUT) {
-                    int_out[at] = (int64_t)o[0];
-                } else {
+            for (int tn = 0; tn < TN; ++tn) {
+                const uint32_t j = j0 + 256 * tn + threadIdx.x;
+                if (j < n_cols && (!square || j > i)) {
+                    const uint64_t at = row_at + j;
+                    uint32_t o[NT];
+                    M::tallies(acc[r][tn], total, o);
+                    if constexpr (OUT == OUT_INT) {
+                        static_cast<int64_t *>(out_v)[at] = (int64_t)o[0];
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < M::NT; ++k)
-                        tallies[at * M::NT + k] = o[k];
+                        for (int k = 0; k < NT; ++k)
+                            static_cast<uint32_t *>(out_v)[at * NT + k] = o[k];
+                    }
                 }
             }
         }
-    }
-}
-
-// =============================================================================================
-// finalize: tallies -> f64, the reference's operation order.  contract(off): rustc never fuses.
-// =============================================================================================
-// (the build passes -ffp-contract=off for the whole file)
-__device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
-{
-    return (double)n / (double)d;
-}
-
-__device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d)  // src/measures.rs:72-77
-{
-    const double p = fin_raw(n, d);
-    return -0.75 * log(1.0 - (4.0 / 3.0) * p);
-}
-
-__device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv)  // :109-112
-{
-    const double P = (double)ts / (double)count_L;
-    const double Q = (double)tv / (double)count_L;
-    return -0.5 * log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
-}
-
-// counts = {A, T, G, C}; sums keep the reference's operand order (target first), :118-190
-__device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
-                                           uint32_t count_P2, uint4 qc, uint4 tc)
-{
-    const uint64_t L = (uint64_t)qc.x + qc.y + qc.z + qc.w + tc.x + tc.y + tc.z + tc.w;
-    const double g_A = ((double)tc.x + (double)qc.x) / (double)L;
-    const double g_C = ((double)tc.w + (double)qc.w) / (double)L;
-    const double g_G = ((double)tc.z + (double)qc.z) / (double)L;
-    const double g_T = ((double)tc.y + (double)qc.y) / (double)L;
-    const double g_R = ((double)tc.x + (double)qc.x + (double)tc.z + (double)qc.z) / (double)L;
-    const double g_Y = ((double)tc.w + (double)qc.w + (double)tc.y + (double)qc.y) / (double)L;
-    const double k1 = 2.0 * g_A * g_G / g_R;
-    const double k2 = 2.0 * g_T * g_C / g_Y;
-    const double k3 = 2.0 * (g_R * g_Y - g_A * g_G * g_Y / g_R - g_T * g_C * g_R / g_Y);
-    const double P1 = (double)count_P1 / (double)count_L;
-    const double P2 = (double)count_P2 / (double)count_L;
-    const double Q = (double)(count_d - (count_P1 + count_P2)) / (double)count_L;
-    const double w1 = 1.0 - P1 / k1 - Q / (2.0 * g_R);
-    const double w2 = 1.0 - P2 / k2 - Q / (2.0 * g_Y);
-    const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
-    double d = -k1 * log(w1) - k2 * log(w2) - k3 * log(w3);
-    if (d == 0.0)
-        d = 0.0;
-    return d;
-}
-
-// one block per row of the launch; threads stride along the row's pairs (coalesced)
-template <int MEASURE>
-__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ tallies,
-                                                       const uint32_t *__restrict__ q_counts,
-                                                       const uint32_t *__restrict__ t_counts,
-                                                       double *__restrict__ out, uint32_t n_cols,
-                                                       uint32_t row_begin, uint64_t out_base,
-                                                       int square)
-{
-    const uint32_t i = row_begin + blockIdx.x;
-    const uint32_t jstart = square ? i + 1 : 0;
-    if (jstart >= n_cols)
-        return;
-    const uint64_t base = square ? tri_row_start(n_cols, i) - out_base
-                                 : (uint64_t)(i - row_begin) * n_cols;
-    uint4 qc = make_uint4(0, 0, 0, 0);
-    if constexpr (MEASURE == DST_TN93)
-        qc = reinterpret_cast<const uint4 *>(q_counts)[i];
-    for (uint32_t k = threadIdx.x; k < n_cols - jstart; k += blockDim.x) {
-        const uint64_t at = base + k;
-        double d;
-        if constexpr (MEASURE == DST_RAW || MEASURE == DST_JC69) {
-            const uint2 v = reinterpret_cast<const uint2 *>(tallies)[at];
-            d = MEASURE == DST_RAW ? fin_raw(v.x, v.y) : fin_jc69(v.x, v.y);
-        } else if constexpr (MEASURE == DST_K80) {
-            const uint32_t *v = tallies + at * 3;
-            d = fin_k80(v[0], v[1], v[2]);
-        } else {
-            const uint4 v = reinterpret_cast<const uint4 *>(tallies)[at];
-            const uint4 tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
-            d = fin_tn93(v.x, v.y, v.z, v.w, qc, tc);
+    } else {
+        // every wave is past the loop's last barrier: the row-tile buffers are dead, reuse them.
+        // Slot layout [pass-row][tn][k][lane]: a lane only ever touches its own column, so LDS
+        // ordering within the wave is all the synchronisation needed.
+        uint32_t *stage = reinterpret_cast<uint32_t *>(smem);
+        double *out = static_cast<double *>(out_v);
+#pragma unroll
+        for (int pass = 0; pass < BM; pass += RP) {
+#pragma unroll
+            for (int rr = 0; rr < RP; ++rr)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    uint32_t o[NT];
+                    M::tallies(acc[pass + rr][tn], total, o);
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        stage[((rr * TN + tn) * NT + k) * 256 + threadIdx.x] = o[k];
+                }
+#pragma unroll 1
+            for (int e = 0; e < RP * TN; ++e) {
+                const int rr = e / TN, tn = e % TN;
+                const uint32_t i = i0 + pass + rr;
+                if (i >= row_end)
+                    break;
+                const uint32_t j = j0 + 256 * tn + threadIdx.x;
+                if (j < n_cols && (!square || j > i)) {
+                    uint32_t o[NT];
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        o[k] = stage[(e * NT + k) * 256 + threadIdx.x];
+                    uint4 qc = make_uint4(0, 0, 0, 0), tc = qc;
+                    if constexpr (OUT == DST_TN93) {
+                        qc = reinterpret_cast<const uint4 *>(q_counts)[i];
+                        tc = reinterpret_cast<const uint4 *>(t_counts)[j];
+                    }
+                    const uint64_t at = square ? (tri_row_start(n_cols, i) - out_base) + (j - i - 1)
+                                               : (uint64_t)(i - row_begin) * n_cols + j;
+                    out[at] = finalize_pair<OUT>(o, qc, tc);
+                }
+            }
         }
-        out[at] = d;
     }
 }
 
@@ -524,22 +557,39 @@ namespace {
 struct Variant {
     int bm, tn, minw;  // rows per tile, columns per lane, waves per SIMD asked of the register allocator
 };
-// tile variants per measure family; [0] is the default.  DESIGN.md "tile variants".
-// [0] is the default: picked on MI355X with tools/kbench.py (profiles/r01/kbench.txt)
-constexpr Variant kVarNHigh[] = {{24, 2, 4}, {16, 2, 4}, {32, 2, 3}, {64, 2, 2}, {32, 4, 2}, {16, 4, 3}};
-constexpr Variant kVarRaw[] = {{12, 2, 4}, {16, 2, 3}, {8, 2, 4}, {32, 2, 2}, {24, 2, 2}, {16, 4, 2}};
-constexpr Variant kVarK80[] = {{12, 2, 3}, {8, 2, 3}, {16, 2, 2}, {10, 2, 4}};
-constexpr Variant kVarTN93[] = {{12, 2, 3}, {8, 2, 4}, {16, 2, 2}, {8, 4, 2}, {10, 2, 4}};
+// [0] is the default: picked on MI355X with tools/kbench.py (profiles/r01/kbench_variants.txt)
+constexpr Variant kVarNHigh[] = {{24, 2, 4}, {16, 2, 4}, {32, 2, 3}};
+constexpr Variant kVarRaw[] = {{12, 2, 4}, {16, 2, 3}, {32, 2, 2}};
+constexpr Variant kVarK80[] = {{12, 2, 3}, {8, 2, 3}};
+constexpr Variant kVarTN93[] = {{12, 2, 3}, {8, 2, 4}, {16, 2, 2}};
 
-template <class M, int BM, int TN, int MINW, bool INT_OUT>
+template <class M, int BM, int TN, int MINW, int OUT>
 hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
 {
-    hipLaunchKernelGGL((pair_kernel<M, BM, TN, MINW, INT_OUT>), dim3(pl.nblocks), dim3(256), 0, stream,
-                       pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_tallies, pl.d_int_out,
-                       (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad, (uint32_t)pl.cols->npad,
-                       (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, (uint32_t)pl.row_end,
-                       pl.out_base, pl.square ? 1 : 0);
+    hipLaunchKernelGGL((pair_kernel<M, BM, TN, MINW, OUT>), dim3(pl.nblocks), dim3(256), 0, stream,
+                       pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_out, pl.rows->counts,
+                       pl.cols->counts, (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad,
+                       (uint32_t)pl.cols->npad, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin,
+                       (uint32_t)pl.row_end, pl.out_base, pl.square ? 1 : 0);
     return hipGetLastError();
+}
+
+// every output form of one (family, tile variant)
+template <class M, int BM, int TN, int MINW>
+hipError_t launch_outputs(int measure, const PairLaunch &pl, hipStream_t stream)
+{
+    if (pl.out_kind == DST_OUT_TALLY)
+        return launch_one<M, BM, TN, MINW, OUT_TALLY>(pl, stream);
+    if constexpr (M::NT == 1) {
+        return launch_one<M, BM, TN, MINW, OUT_INT>(pl, stream);
+    } else if constexpr (M::NT == 2) {
+        return measure == DST_RAW ? launch_one<M, BM, TN, MINW, DST_RAW>(pl, stream)
+                                  : launch_one<M, BM, TN, MINW, DST_JC69>(pl, stream);
+    } else if constexpr (M::NT == 3) {
+        return launch_one<M, BM, TN, MINW, DST_K80>(pl, stream);
+    } else {
+        return launch_one<M, BM, TN, MINW, DST_TN93>(pl, stream);
+    }
 }
 
 }  // namespace
@@ -578,9 +628,9 @@ TileShape tile_shape(int measure, int variant)
     return TileShape{v.bm, 256 * v.tn};
 }
 
-#define DST_CASE(M, BM_, TN_, W_, IO)                               \
+#define DST_CASE(M, BM_, TN_, W_)                                   \
     if (v.bm == BM_ && v.tn == TN_ && v.minw == W_)                 \
-        return launch_one<M, BM_, TN_, W_, IO>(pl, stream);
+        return launch_outputs<M, BM_, TN_, W_>(measure, pl, stream);
 
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream)
 {
@@ -588,52 +638,22 @@ hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStrea
     switch (measure) {
     case DST_N:
     case DST_N_HIGH:
-        if (pl.d_int_out) {
-            DST_CASE(MNHigh, 16, 2, 4, true) DST_CASE(MNHigh, 32, 2, 3, true) DST_CASE(MNHigh, 24, 2, 4, true)
-            DST_CASE(MNHigh, 64, 2, 2, true) DST_CASE(MNHigh, 32, 4, 2, true) DST_CASE(MNHigh, 16, 4, 3, true)
-        } else {
-            DST_CASE(MNHigh, 16, 2, 4, false) DST_CASE(MNHigh, 32, 2, 3, false) DST_CASE(MNHigh, 24, 2, 4, false)
-            DST_CASE(MNHigh, 64, 2, 2, false) DST_CASE(MNHigh, 32, 4, 2, false) DST_CASE(MNHigh, 16, 4, 3, false)
-        }
+        DST_CASE(MNHigh, 24, 2, 4) DST_CASE(MNHigh, 16, 2, 4) DST_CASE(MNHigh, 32, 2, 3)
         break;
     case DST_RAW:
     case DST_JC69:
-        DST_CASE(MRaw, 12, 2, 4, false) DST_CASE(MRaw, 16, 2, 3, false) DST_CASE(MRaw, 8, 2, 4, false)
-        DST_CASE(MRaw, 32, 2, 2, false) DST_CASE(MRaw, 24, 2, 2, false) DST_CASE(MRaw, 16, 4, 2, false)
+        DST_CASE(MRaw, 12, 2, 4) DST_CASE(MRaw, 16, 2, 3) DST_CASE(MRaw, 32, 2, 2)
         break;
     case DST_K80:
-        DST_CASE(MK80, 8, 2, 3, false) DST_CASE(MK80, 16, 2, 2, false) DST_CASE(MK80, 12, 2, 3, false)
-        DST_CASE(MK80, 10, 2, 4, false)
+        DST_CASE(MK80, 12, 2, 3) DST_CASE(MK80, 8, 2, 3)
         break;
     case DST_TN93:
-        DST_CASE(MTN93, 12, 2, 3, false) DST_CASE(MTN93, 8, 2, 4, false) DST_CASE(MTN93, 16, 2, 2, false)
-        DST_CASE(MTN93, 8, 4, 2, false) DST_CASE(MTN93, 10, 2, 4, false)
+        DST_CASE(MTN93, 12, 2, 3) DST_CASE(MTN93, 8, 2, 4) DST_CASE(MTN93, 16, 2, 2)
         break;
     default: break;
     }
     return hipErrorInvalidValue;
 }
 #undef DST_CASE
-
-hipError_t launch_finalize(int measure, const PairLaunch &pl, double *d_out, hipStream_t stream)
-{
-    const unsigned rows = (unsigned)(pl.row_end - pl.row_begin);
-    if (rows == 0)
-        return hipSuccess;
-    const uint32_t *qc = pl.rows->counts, *tc = pl.cols->counts;
-#define DST_FIN(MEAS)                                                                            \
-    hipLaunchKernelGGL((finalize_kernel<MEAS>), dim3(rows), dim3(256), 0, stream, pl.d_tallies,  \
-                       qc, tc, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, pl.out_base, \
-                       pl.square ? 1 : 0)
-    switch (measure) {
-    case DST_RAW: DST_FIN(DST_RAW); break;
-    case DST_JC69: DST_FIN(DST_JC69); break;
-    case DST_K80: DST_FIN(DST_K80); break;
-    case DST_TN93: DST_FIN(DST_TN93); break;
-    default: return hipErrorInvalidValue;
-    }
-#undef DST_FIN
-    return hipGetLastError();
-}
 
 }  // namespace dst

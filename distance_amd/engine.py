@@ -137,9 +137,6 @@ class Engine:
     def set_variant(self, variant: int):
         self._check(self._lib.dst_set_variant(self._h, variant))
 
-    def set_scratch_limit(self, nbytes: int):
-        self._check(self._lib.dst_set_scratch_limit(self._h, nbytes))
-
     # ---- input -----------------------------------------------------------------------------
     def upload(self, slot: int, codes: np.ndarray, base_counts: np.ndarray | None = None):
         """codes: (n, L) uint8 Paradis codes (any row stride); base_counts: (n, 4) {A,T,G,C}."""

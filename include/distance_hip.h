@@ -57,8 +57,9 @@ typedef enum {
 
 /* What a run writes per pair, in canonical order:
  *  DST_OUT_DISTANCE: 8 bytes — the payload of FloatInt (src/measures.rs:5-9): int64 for n/n_high,
- *                    f64 for raw/jc69/k80/tn93 finalised ON DEVICE (reference operation order,
- *                    ocml log/sqrt: within 1e-12 of the reference, not bit-identical).
+ *                    f64 for raw/jc69/k80/tn93 finalised ON DEVICE in the pair kernel's epilogue
+ *                    (reference operation order, ocml log/sqrt: within 1e-12 of the reference,
+ *                    not bit-identical).
  *  DST_OUT_TALLY:    dst_tally_width(measure) x uint32 site tallies, bit-exact integers:
  *                      n, n_high : {d}
  *                      raw, jc69 : {n, d}                        (src/measures.rs:57-66)
@@ -79,9 +80,6 @@ const char *dst_status_string(int status);
 int dst_create(int device, dst_ctx **ctx);
 int dst_destroy(dst_ctx *ctx);
 const char *dst_last_error(const dst_ctx *ctx); /* ctx may be NULL: last dst_create failure */
-/* upper bound, in bytes, of the device scratch one pair-kernel launch may use for tallies
- * (default 32 GiB; runs are cut into row slabs that fit) */
-int dst_set_scratch_limit(dst_ctx *ctx, size_t bytes);
 /* kernel tile variant: 0 = default for the measure; see DESIGN.md "tile variants" */
 int dst_set_variant(dst_ctx *ctx, int variant);
 int dst_variant_count(int measure);
@@ -128,8 +126,9 @@ int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uin
                       uint64_t row_end, int out_kind, void *h_out, size_t out_capacity_bytes);
 /* bytes a run writes */
 size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs);
-/* milliseconds of the pair kernel(s) / the pack kernel of the most recent run / upload on this
- * context, from HIP events recorded on the launch stream (bench.py's roofline leg) */
+/* milliseconds of the pair kernel of the most recent run and of the pack kernel of the most recent
+ * upload on this context, from HIP events recorded on the launch stream (bench.py's roofline leg);
+ * *finalize_ms is always 0: finalisation is fused into the pair kernel's epilogue */
 int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *pack_ms);
 
 /* Diagnostic: the tile schedule one pair-kernel launch would use for rows [row_begin,row_end)

@@ -161,18 +161,6 @@ def test_row_ranges_and_partition_concatenate(eng):
         assert eng.run_square(m, 5, 5).shape == (0,)
 
 
-def test_slabs_give_identical_output(eng):
-    codes = random_alignment(200, 150, 22)
-    eng.upload(0, codes)
-    full = {m: eng.run_square(m) for m in ("raw", "tn93")}
-    eng.set_scratch_limit(4096)   # forces many row slabs through the tally scratch
-    try:
-        for m in full:
-            assert np.array_equal(eng.run_square(m), full[m], equal_nan=True)
-    finally:
-        eng.set_scratch_limit(32 << 30)
-
-
 def test_every_tile_variant_agrees(eng):
     codes = random_alignment(600, 260, 23, divergence=0.3)
     eng.upload(0, codes)
@@ -324,15 +312,11 @@ def test_very_long_alignment_rect_and_stream(eng):
 
 
 def test_many_records_short_alignment(eng):
-    """C5-shaped: many records x short alignment; rows cross several scratch slabs."""
+    """C5-shaped: many records x short alignment (18M pairs, epilogue-dominated tiles)."""
     n, L = 6000, 200
     codes = random_alignment(n, L, 93, divergence=0.1)
     eng.upload(0, codes)
-    eng.set_scratch_limit(32 << 20)      # ~4M pairs per slab -> 5 slabs
-    try:
-        jc = eng.run_square("jc69")
-    finally:
-        eng.set_scratch_limit(32 << 30)
+    jc = eng.run_square("jc69")
     tl = eng.run_square("jc69", tallies=True)
     with np.errstate(invalid="ignore", divide="ignore"):
         p = tl[:, 0] / tl[:, 1].astype(np.float64)
