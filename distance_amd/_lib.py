@@ -44,6 +44,7 @@ _SIGS = {
     "dst_last_error": (C.c_char_p, [_vp]),
     "dst_set_variant": (C.c_int, [_vp, C.c_int]),
     "dst_variant_count": (C.c_int, [C.c_int]),
+    "dst_set_ksplit": (C.c_int, [_vp, C.c_int]),
     "dst_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "dst_upload_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
     "dst_set_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

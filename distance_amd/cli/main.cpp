@@ -637,42 +637,70 @@ int main(int argc, char **argv)
     } else {
         // ---- stream(): src/lib.rs:269-365; stream_fasta(): src/fastaio.rs:215-286 ---------------
         const Alignment &ref = loaded[0];
-        cli::FastaReader reader(stream_fh);
-        cli::FastaRecord rec;
-        size_t record_counter = 0;
         const size_t batch_records = std::max<size_t>(1, std::min<size_t>(4096, a.slab_pairs / std::max<size_t>(ref.n, 1)));
-        bool eof = false;
-        while (!eof) {
-            Alignment batch;
-            batch.width = ref.width;
-            while (batch.n < batch_records) {
-                const int rc = reader.next(rec);
-                if (rc < 0)
-                    die_message(reader.error());
-                if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty())) {
-                    eof = true;
-                    break;
+        // reader thread: parse + encode batch k+1 while the GPUs and the formatting pool work on
+        // batch k (the reference's stream_fasta thread + bounded channel, src/lib.rs:272, 290-307)
+        std::mutex qmu;
+        std::condition_variable qcv;
+        std::deque<std::unique_ptr<Alignment>> queue;
+        bool reader_done = false;
+        size_t record_counter = 0;
+        std::thread reader_thread([&] {
+            cli::FastaReader reader(stream_fh);
+            cli::FastaRecord rec;
+            bool eof = false;
+            while (!eof) {
+                auto batch = std::make_unique<Alignment>();
+                batch->width = ref.width;
+                while (batch->n < batch_records) {
+                    const int rc = reader.next(rec);
+                    if (rc < 0)
+                        die_message(reader.error());
+                    if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty())) {
+                        eof = true;
+                        break;
+                    }
+                    record_counter += 1;
+                    if (rec.seq.size() != ref.width)
+                        die_message(err_lengths(rec.seq.size(), ref.width));  // src/fastaio.rs:246-248
+                    encode_into(rec, table, *batch, measure == DST_TN93);    // tn93: raw upper-case counts (:136-142)
                 }
-                record_counter += 1;
-                if (rec.seq.size() != ref.width)
-                    die_message(err_lengths(rec.seq.size(), ref.width));
-                encode_into(rec, table, batch, measure == DST_TN93);  // tn93: raw upper-case counts (:136-142)
+                if (batch->n == 0)
+                    break;
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [&] { return queue.size() < 2; });
+                queue.push_back(std::move(batch));
+                qcv.notify_all();
             }
-            if (batch.n == 0)
-                break;
+            std::lock_guard<std::mutex> lk(qmu);
+            reader_done = true;
+            qcv.notify_all();
+        });
+        for (;;) {
+            std::unique_ptr<Alignment> batch;
+            {
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [&] { return !queue.empty() || reader_done; });
+                if (queue.empty())
+                    break;
+                batch = std::move(queue.front());
+                queue.pop_front();
+                qcv.notify_all();
+            }
             for (int g = 0; g < G; ++g)
-                gpus[g].check(dst_upload(gpus[g].h, 1, batch.codes.data(), batch.n, batch.width, batch.width,
-                                         measure == DST_TN93 ? batch.counts.data() : nullptr),
+                gpus[g].check(dst_upload(gpus[g].h, 1, batch->codes.data(), batch->n, batch->width, batch->width,
+                                         measure == DST_TN93 ? batch->counts.data() : nullptr),
                               "upload batch");
             Job sj = job;
             sj.square = false;
             sj.swap_ids = true;          // id1 = loaded record, id2 = streamed record (src/lib.rs:327-330)
-            sj.rows = &batch;            // streamed record outer ...
+            sj.rows = batch.get();       // streamed record outer ...
             sj.cols = &ref;              // ... loaded record inner (src/lib.rs:323-324)
-            sj.row_counts = measure == DST_TN93 ? batch.counts.data() : nullptr;
+            sj.row_counts = measure == DST_TN93 ? batch->counts.data() : nullptr;
             sj.col_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
             run_slabs(gpus, sj, 1, 0, a.slab_pairs, wr);
         }
+        reader_thread.join();
         if (record_counter == 0)
             die_message("Empty FASTA file");  // src/fastaio.rs:281-283
     }

@@ -33,6 +33,9 @@ struct dst_ctx {
     std::vector<Schedule> schedules;
     uint64_t schedule_clock = 0;
     int variant = 0;
+    int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
+    uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
+    size_t scratch_bytes = 0;
     hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;
@@ -256,11 +259,40 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
     pl.d_out = d_out;
     pl.d_blocks = d_blocks;
     pl.nblocks = nblocks;
+    // Few tiles but a long alignment (small sets, streamed batches): split the sweep over L so the
+    // launch still fills the 256 CUs; partial tallies are combined with integer atomics (exact).
+    uint32_t ksplit = 1;
+    if (ctx->ksplit >= 1) {
+        ksplit = (uint32_t)ctx->ksplit;
+    } else if (nblocks && nblocks < 2048 && rows.nchunks >= 16) {
+        ksplit = (uint32_t)std::min<uint64_t>({(2048 + nblocks - 1) / nblocks, rows.nchunks / 8, (uint64_t)64});
+    }
+    ksplit = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(ksplit, 1), std::max<size_t>(rows.nchunks, 1));
+    pl.ksplit = ksplit;
+    const bool f64_out = out_kind == DST_OUT_DISTANCE && !measure_is_int(measure);
+    if (nblocks && ksplit > 1) {
+        if (f64_out) {
+            const size_t want = (size_t)total_pairs * tally_width(measure) * sizeof(uint32_t);
+            if (ctx->scratch_bytes < want) {
+                HIP_TRY(ctx, hipStreamSynchronize(stream));  // an earlier run may still read the old one
+                rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes, want);
+                if (rc)
+                    return rc;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, want, stream));
+            pl.out_kind = DST_OUT_TALLY;
+            pl.d_out = ctx->scratch;
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(d_out, 0, need, stream));
+        }
+    }
     if (nblocks) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
         HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
         ctx->timed_pair = true;
+        if (ksplit > 1 && f64_out)
+            HIP_TRY(ctx, launch_finalize(measure, pl, ctx->scratch, (double *)d_out, stream));
     }
     if (!stream_v)
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -373,6 +405,8 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
+    if (ctx->scratch)
+        (void)hipFree(ctx->scratch);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
     for (auto &ev : ctx->ev)
@@ -385,6 +419,14 @@ int dst_destroy(dst_ctx *ctx)
 }
 
 int dst_variant_count(int measure) { return variant_count(measure); }
+
+int dst_set_ksplit(dst_ctx *ctx, int ksplit)
+{
+    if (!ctx || ksplit < 0)
+        return DST_ERR_ARG;
+    ctx->ksplit = ksplit;
+    return DST_OK;
+}
 
 int dst_set_variant(dst_ctx *ctx, int variant)
 {

@@ -65,6 +65,7 @@ struct PairLaunch {
     void *d_out;                  // first pair of this launch
     const BlockDesc *d_blocks;
     uint32_t nblocks;
+    uint32_t ksplit = 1;          // > 1: split-L launch, partial tallies added atomically
 };
 
 // ---- kernel launchers (dst_kernels.hip) -----------------------------------------------------
@@ -72,6 +73,8 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
                        unsigned long long *d_first_bad, hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
+hipError_t launch_finalize(int measure, const PairLaunch &pl, const uint32_t *d_tallies, double *d_out,
+                           hipStream_t stream);
 TileShape tile_shape(int measure, int variant);
 int variant_count(int measure);
 

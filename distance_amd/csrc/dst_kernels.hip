@@ -326,8 +326,10 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     return d;
 }
 
-constexpr int OUT_TALLY = -1;  // uint32 x NT site tallies per pair
-constexpr int OUT_INT = -2;    // int64 (n / n_high)
+constexpr int OUT_TALLY = -1;      // uint32 x NT site tallies per pair
+constexpr int OUT_INT = -2;        // int64 (n / n_high)
+constexpr int OUT_TALLY_ADD = -3;  // split-L launch: atomicAdd partial tallies into a zeroed buffer
+constexpr int OUT_INT_ADD = -4;    // split-L launch: atomicAdd partial counts into zeroed int64
 // OUT >= 0: the measure id whose f64 distance the epilogue writes
 
 template <int MEASURE>
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     const BlockDesc *__restrict__ blocks, void *__restrict__ out_v,
     const uint32_t *__restrict__ q_counts, const uint32_t *__restrict__ t_counts, uint32_t nchunks,
     uint32_t q_npad, uint32_t t_npad, uint32_t n_cols, uint32_t row_begin, uint32_t row_end,
-    uint64_t out_base, int square)
+    uint64_t out_base, int square, uint32_t ksplit)
 {
     constexpr int NP = M::NP, NC = M::NC, NT = M::NT;
     constexpr int QV = NP * BM;               // uint4 per staged row tile
@@ -373,9 +375,18 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     __shared__ uint4 smem[SMEM_U4];
     uint4 (*qs)[NP][BM] = reinterpret_cast<uint4 (*)[NP][BM]>(smem);
 
-    const uint32_t i0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].i0);
-    const uint32_t j0 = __builtin_amdgcn_readfirstlane(blocks[blockIdx.x].j0);
-    if (i0 == 0xFFFFFFFFu)
+    // split-L launches (few tiles, long alignments): ksplit consecutive blocks share a tile and
+    // each sweeps its own range of chunks; their partial tallies meet in integer atomics (exact).
+    uint32_t tile = blockIdx.x, c_begin = 0, c_end = nchunks;
+    if constexpr (OUT == OUT_TALLY_ADD || OUT == OUT_INT_ADD) {
+        tile = blockIdx.x / ksplit;
+        const uint32_t part = blockIdx.x - tile * ksplit;
+        c_begin = (uint32_t)(((uint64_t)nchunks * part) / ksplit);
+        c_end = (uint32_t)(((uint64_t)nchunks * (part + 1)) / ksplit);
+    }
+    const uint32_t i0 = __builtin_amdgcn_readfirstlane(blocks[tile].i0);
+    const uint32_t j0 = __builtin_amdgcn_readfirstlane(blocks[tile].j0);
+    if (i0 == 0xFFFFFFFFu || c_begin >= c_end)
         return;
 
     uint32_t acc[BM][TN][NC];
@@ -396,12 +407,12 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     for (int k = 0; k < QL; ++k) {
         const int e = (int)threadIdx.x + 256 * k;
         const int sp = e / BM, sr = e % BM;
-        qsrc[k] = qpl + (size_t)(M::P0 + (e < QV ? sp : 0)) * q_ps + i0 + sr;
+        qsrc[k] = qpl + (size_t)(M::P0 + (e < QV ? sp : 0)) * q_ps + (size_t)c_begin * q_npad + i0 + sr;
         qdst0[k] = &qs[0][e < QV ? sp : 0][sr];
     }
-    const uint4 *tchunk = tpl + (size_t)M::P0 * t_ps + j0 + threadIdx.x;  // += t_npad per chunk
+    const uint4 *tchunk = tpl + (size_t)M::P0 * t_ps + (size_t)c_begin * t_npad + j0 + threadIdx.x;
 
-    // prologue: chunk 0 of the row tile
+    // prologue: first chunk of the row tile
 #pragma unroll
     for (int k = 0; k < QL; ++k)
         if ((int)threadIdx.x + 256 * k < QV)
@@ -409,9 +420,9 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     __syncthreads();
 
 #pragma unroll 1
-    for (uint32_t c = 0; c < nchunks; ++c) {
+    for (uint32_t c = 0; c < c_end - c_begin; ++c) {
         const uint32_t buf = c & 1u;
-        const bool more = c + 1 < nchunks;
+        const bool more = c + 1 < c_end - c_begin;
         uint4 qnext[QL];
         if (more) {
 #pragma unroll
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
         __syncthreads();
     }
 
-    const uint32_t total = nchunks * kChunkSites;  // padded sites are N on both sides: "share"
+    const uint32_t total = (c_end - c_begin) * kChunkSites;  // padded sites are N on both sides: "share"
     if constexpr (OUT < 0) {
 #pragma unroll
         for (int r = 0; r < BM; ++r) {
@@ -477,6 +488,12 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
                     M::tallies(acc[r][tn], total, o);
                     if constexpr (OUT == OUT_INT) {
                         static_cast<int64_t *>(out_v)[at] = (int64_t)o[0];
+                    } else if constexpr (OUT == OUT_INT_ADD) {
+                        atomicAdd(static_cast<unsigned long long *>(out_v) + at, (unsigned long long)o[0]);
+                    } else if constexpr (OUT == OUT_TALLY_ADD) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+                            atomicAdd(static_cast<uint32_t *>(out_v) + at * NT + k, o[k]);
                     } else {
 #pragma unroll
                         for (int k = 0; k < NT; ++k)
@@ -529,6 +546,38 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     }
 }
 
+// tallies -> f64 for split-L launches (their partial tallies meet in a scratch buffer first);
+// one block per row of the launch, threads stride along the row's pairs (coalesced)
+template <int MEASURE>
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ tallies,
+                                                       const uint32_t *__restrict__ q_counts,
+                                                       const uint32_t *__restrict__ t_counts,
+                                                       double *__restrict__ out, uint32_t n_cols,
+                                                       uint32_t row_begin, uint64_t out_base,
+                                                       int square)
+{
+    constexpr int NT = MEASURE == DST_K80 ? 3 : MEASURE == DST_TN93 ? 4 : 2;
+    const uint32_t i = row_begin + blockIdx.x;
+    const uint32_t jstart = square ? i + 1 : 0;
+    if (jstart >= n_cols)
+        return;
+    const uint64_t base = square ? tri_row_start(n_cols, i) - out_base
+                                 : (uint64_t)(i - row_begin) * n_cols;
+    uint4 qc = make_uint4(0, 0, 0, 0), tc = qc;
+    if constexpr (MEASURE == DST_TN93)
+        qc = reinterpret_cast<const uint4 *>(q_counts)[i];
+    for (uint32_t k = threadIdx.x; k < n_cols - jstart; k += blockDim.x) {
+        const uint64_t at = base + k;
+        uint32_t o[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            o[t] = tallies[at * NT + t];
+        if constexpr (MEASURE == DST_TN93)
+            tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
+        out[at] = finalize_pair<MEASURE>(o, qc, tc);
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -570,7 +619,18 @@ hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
                        pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_out, pl.rows->counts,
                        pl.cols->counts, (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad,
                        (uint32_t)pl.cols->npad, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin,
-                       (uint32_t)pl.row_end, pl.out_base, pl.square ? 1 : 0);
+                       (uint32_t)pl.row_end, pl.out_base, pl.square ? 1 : 0, (uint32_t)pl.ksplit);
+    return hipGetLastError();
+}
+
+template <class M, int BM, int TN, int MINW, int OUT>
+hipError_t launch_split(const PairLaunch &pl, hipStream_t stream)
+{
+    hipLaunchKernelGGL((pair_kernel<M, BM, TN, MINW, OUT>), dim3(pl.nblocks * (unsigned)pl.ksplit), dim3(256), 0,
+                       stream, pl.rows->planes, pl.cols->planes, pl.d_blocks, pl.d_out, pl.rows->counts,
+                       pl.cols->counts, (uint32_t)pl.rows->nchunks, (uint32_t)pl.rows->npad,
+                       (uint32_t)pl.cols->npad, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin,
+                       (uint32_t)pl.row_end, pl.out_base, pl.square ? 1 : 0, (uint32_t)pl.ksplit);
     return hipGetLastError();
 }
 
@@ -578,6 +638,13 @@ hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
 template <class M, int BM, int TN, int MINW>
 hipError_t launch_outputs(int measure, const PairLaunch &pl, hipStream_t stream)
 {
+    if (pl.ksplit > 1) {  // the caller zeroed the buffer; f64 goes through a tally scratch
+        if constexpr (M::NT == 1) {
+            if (pl.out_kind == DST_OUT_DISTANCE)
+                return launch_split<M, BM, TN, MINW, OUT_INT_ADD>(pl, stream);
+        }
+        return launch_split<M, BM, TN, MINW, OUT_TALLY_ADD>(pl, stream);
+    }
     if (pl.out_kind == DST_OUT_TALLY)
         return launch_one<M, BM, TN, MINW, OUT_TALLY>(pl, stream);
     if constexpr (M::NT == 1) {
@@ -655,5 +722,26 @@ hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStrea
     return hipErrorInvalidValue;
 }
 #undef DST_CASE
+
+hipError_t launch_finalize(int measure, const PairLaunch &pl, const uint32_t *d_tallies, double *d_out,
+                           hipStream_t stream)
+{
+    const unsigned rows = (unsigned)(pl.row_end - pl.row_begin);
+    if (rows == 0)
+        return hipSuccess;
+#define DST_FIN(MEAS)                                                                              \
+    hipLaunchKernelGGL((finalize_kernel<MEAS>), dim3(rows), dim3(256), 0, stream, d_tallies,       \
+                       pl.rows->counts, pl.cols->counts, d_out, (uint32_t)pl.cols->n,              \
+                       (uint32_t)pl.row_begin, pl.out_base, pl.square ? 1 : 0)
+    switch (measure) {
+    case DST_RAW: DST_FIN(DST_RAW); break;
+    case DST_JC69: DST_FIN(DST_JC69); break;
+    case DST_K80: DST_FIN(DST_K80); break;
+    case DST_TN93: DST_FIN(DST_TN93); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DST_FIN
+    return hipGetLastError();
+}
 
 }  // namespace dst

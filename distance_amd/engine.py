@@ -137,6 +137,10 @@ class Engine:
     def set_variant(self, variant: int):
         self._check(self._lib.dst_set_variant(self._h, variant))
 
+    def set_ksplit(self, ksplit: int):
+        """0 = automatic split over L for launches with few tiles, 1 = off, k = force."""
+        self._check(self._lib.dst_set_ksplit(self._h, ksplit))
+
     # ---- input -----------------------------------------------------------------------------
     def upload(self, slot: int, codes: np.ndarray, base_counts: np.ndarray | None = None):
         """codes: (n, L) uint8 Paradis codes (any row stride); base_counts: (n, 4) {A,T,G,C}."""

@@ -83,6 +83,10 @@ const char *dst_last_error(const dst_ctx *ctx); /* ctx may be NULL: last dst_cre
 /* kernel tile variant: 0 = default for the measure; see DESIGN.md "tile variants" */
 int dst_set_variant(dst_ctx *ctx, int variant);
 int dst_variant_count(int measure);
+/* split-L factor: launches with few tiles and a long alignment (small sets, streamed batches) cut
+ * the sweep over L into `ksplit` parts whose partial integer tallies are combined with atomics
+ * (exact).  0 = automatic (default), 1 = never split, k > 1 = force. */
+int dst_set_ksplit(dst_ctx *ctx, int ksplit);
 
 /* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */
 /* codes: row-major n x len Paradis bytes, rows row_stride bytes apart (>= len).

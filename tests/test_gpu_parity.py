@@ -175,6 +175,27 @@ def test_every_tile_variant_agrees(eng):
         assert np.array_equal(ref.astype(np.uint64), oracle_tallies_square(m, codes))
 
 
+def test_split_over_L_agrees_with_single_sweep(eng):
+    """Split-L launches (automatic for few tiles x long L) combine partial tallies exactly."""
+    codes = uniform_codes(70, 5000, 24)
+    b = uniform_codes(9, 5000, 25)
+    eng.upload(0, codes)
+    eng.upload(1, b)
+    for m in ALL:
+        ref_d = ref_t = ref_r = None
+        for k in (1, 0, 2, 7, 40):
+            eng.set_ksplit(k)
+            d, t = eng.run_square(m), eng.run_square(m, tallies=True)
+            r = eng.run_rect(m, row_begin=2, row_end=8)
+            if ref_d is None:
+                ref_d, ref_t, ref_r = d, t, r
+            assert np.array_equal(d, ref_d, equal_nan=True), (m, k)
+            assert np.array_equal(t, ref_t), (m, k)
+            assert np.array_equal(r, ref_r, equal_nan=True), (m, k)
+        eng.set_ksplit(0)
+        assert np.array_equal(ref_t.astype(np.uint64), oracle_tallies_square(m, codes)), m
+
+
 def test_rectangle_and_stream_orders(eng):
     a = random_alignment(37, 333, 31)
     b = random_alignment(21, 333, 32)
