@@ -11,6 +11,8 @@
 
 namespace cli {
 
+constexpr int kFixed12Max = 336;  // sign + 309 digits + '.' + 12 digits + NUL, rounded up
+
 inline int fmt_u64(uint64_t v, char *out)
 {
     char tmp[24];
@@ -33,7 +35,7 @@ inline int fmt_i64(int64_t v, char *out)
     return fmt_u64((uint64_t)v, out);
 }
 
-// writes at most 40 chars, returns the length
+// `out` must hold kFixed12Max bytes (DBL_MAX prints 309 integer digits); returns the length
 inline int fmt_fixed12(double v, char *out)
 {
     if (std::isnan(v)) {
@@ -53,7 +55,7 @@ inline int fmt_fixed12(double v, char *out)
     const uint64_t m = (uint64_t)std::ldexp(fr, 53);        // exact 53-bit integer (0 for a == 0)
     const int sh = 53 - e2;                                 // a = m * 2^-sh
     if (a != 0.0 && sh <= 0)                                // >= 2^53: rare, let libc do it
-        return n + std::snprintf(out + n, 400, "%.12f", a);
+        return n + std::snprintf(out + n, (size_t)(kFixed12Max - n), "%.12f", a);
     unsigned __int128 R = 0;
     if (a != 0.0 && sh < 128) {
         const unsigned __int128 P = (unsigned __int128)m * 1000000000000ull;  // < 2^93

@@ -367,7 +367,7 @@ void format_slab(const Job &job, Slab &slab)
     }
     auto work = [&](size_t k) {
         std::string &out = parts[k];
-        char num[64];
+        char num[cli::kFixed12Max];
         for (uint64_t i = cut[k]; i < cut[k + 1]; ++i) {
             const uint64_t j0 = job.square ? i + 1 : 0;
             uint64_t p = job.square ? dst_square_row_start(ncols, i) - dst_square_row_start(ncols, slab.rb)

@@ -93,7 +93,8 @@ void free_set(DeviceSet &s)
 // (re)allocate the planes / counts of a set for n x len
 int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
 {
-    const size_t nchunks = (len + kChunkSites - 1) / kChunkSites;
+    // an empty alignment (len == 0) still gets one all-N chunk so every kernel has something to read
+    const size_t nchunks = std::max<size_t>(1, (len + kChunkSites - 1) / kChunkSites);
     const size_t npad = ((n + 256 + kPadRecords - 1) / kPadRecords) * kPadRecords;
     const size_t bytes = (size_t)PL_COUNT * nchunks * npad * sizeof(uint4);
     if (!s.planes || s.planes_bytes < bytes || s.npad != npad || s.nchunks != nchunks) {

@@ -150,7 +150,8 @@ int dst_plan_tiles(int square, uint64_t row_begin, uint64_t row_end, uint64_t n_
 int dst_finalize(int measure, const uint32_t *tallies, const uint32_t *q_counts,
                  const uint32_t *t_counts, double *as_float, int64_t *as_int);
 /* One TSV field as gather_write prints it (src/lib.rs:626-633): `{}` / `{:.12}` incl. Rust's
- * "NaN", "inf", "-inf", "-0.000000000000".  Returns the length written (no NUL counted). */
+ * "NaN", "inf", "-inf", "-0.000000000000".  snprintf semantics: returns the length of the full text
+ * (no NUL counted); if that is >= cap the text was truncated to cap-1 characters. */
 int dst_format_distance(int measure, double as_float, int64_t as_int, char *buf, size_t cap);
 
 #ifdef __cplusplus

@@ -140,6 +140,15 @@ def test_single_record_and_identical_records(eng):
     assert eng.run_square("n")[0] == 0
 
 
+def test_zero_width_alignment(eng):
+    """Records with empty sequences: every tally is 0, raw = 0/0 = NaN, n = 0."""
+    eng.upload(0, np.zeros((3, 0), np.uint8))
+    assert np.array_equal(eng.run_square("n_high"), np.zeros(3, np.int64))
+    assert np.all(np.isnan(eng.run_square("raw")))
+    assert np.all(np.isnan(eng.run_square("tn93")))
+    assert not eng.run_square("k80", tallies=True).any()
+
+
 def test_nan_inf_cases_match(eng):
     a = oracle.encode(b"ACGTACGTACGTACGTAAAA")
     b = oracle.encode(b"CATGCATGCATGCATGAAAA")   # p = 0.8 -> jc69 NaN
