@@ -142,6 +142,7 @@ def main():
                     help="debug: N ranks share GPU 0 and exchange over gloo via host staging (checks the "
                          "multi-rank indexing on a 1-GPU box; RCCL itself needs one GPU per rank)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-computes sampled rows and compares")
+    ap.add_argument("--wire-f64", action="store_true", help="N>1: always send 8-byte results, never uint16 tallies")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,33 +189,54 @@ def main():
     # send/recv on RCCL's own stream) while sub-slab k+1 is being computed.
     chunks = args.chunks if world > 1 else 1
     sub_rows, sub_offs = chunked_layout(n, world, chunks)
+    # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
+    # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
+    # same device arithmetic as a direct run).  k80 (6 B) / tn93 (8 B) travel as f64.
+    width = da.tally_width(measure)
+    wire16 = world > 1 and L < 65536 and 2 * width < 8 and not args.wire_f64
     if world == 1:
         full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
         local_out = full_out
+        wire_local = wire_full = None
     elif rank == 0:
         full_out = torch.empty(total_pairs, dtype=out_dtype, device=dev)
         local_out = full_out[offsets[0]:offsets[1]]          # rank 0 computes straight into place
+        wire_local = None
+        wire_full = torch.empty((total_pairs, width), dtype=torch.uint16, device=dev) if wire16 else None
     else:
         full_out = None
-        local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+        local_out = None if wire16 else torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+        wire_local = torch.empty((max(my_pairs, 1), width), dtype=torch.uint16, device=dev) if wire16 else None
+        wire_full = None
     base = offsets[rank]
 
     staged = []
 
     def rehearse_chunk(k):
-        # same indexing as post_chunk, but through pinned host tensors over gloo
+        # same indexing as post_chunk, but through host tensors over gloo
         torch.cuda.synchronize()
         if rank == 0:
             host = []
             for r in range(1, world):
                 lo, hi = sub_offs[r][k], sub_offs[r][k + 1]
                 if hi > lo:
-                    t = torch.empty(hi - lo, dtype=out_dtype)
+                    t = torch.empty((hi - lo, width), dtype=torch.uint16) if wire16 else torch.empty(hi - lo, dtype=out_dtype)
                     staged.append(((lo, hi), t))
                     host.append(dist.P2POp(dist.irecv, t, r))
             return dist.batch_isend_irecv(host) if host else []
         lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
-        return dist.batch_isend_irecv([dist.P2POp(dist.isend, local_out[lo:hi].cpu(), 0)]) if hi > lo else []
+        src = wire_local if wire16 else local_out
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend, src[lo:hi].cpu(), 0)]) if hi > lo else []
+
+    def finalize_received(k):
+        # rank 0: sub-slab k of every other rank has landed as uint16 tallies -> f64 / int64 in place
+        for r in range(1, world):
+            r0, r1 = sub_rows[r][k], sub_rows[r][k + 1]
+            lo, hi = sub_offs[r][k], sub_offs[r][k + 1]
+            if hi > lo:
+                eng.finalize_device(measure, r0, r1, wire_full.data_ptr() + 2 * width * lo,
+                                    full_out.data_ptr() + 8 * lo, 8 * (hi - lo), tally_kind=da.OUT_TALLY16,
+                                    stream=stream)
 
     def step():
         eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
@@ -222,18 +244,28 @@ def main():
         for k in range(chunks):
             r0, r1 = sub_rows[rank][k], sub_rows[rank][k + 1]
             lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
-            if hi > lo:
+            if hi > lo and wire16 and rank != 0:
+                eng.run_square_device(measure, r0, r1, wire_local.data_ptr() + 2 * width * lo, 2 * width * (hi - lo),
+                                      stream=stream, out_kind=da.OUT_TALLY16)
+            elif hi > lo:
                 eng.run_square_device(measure, r0, r1, local_out.data_ptr() + 8 * lo, 8 * (hi - lo), stream=stream)
             if world > 1 and not args.rehearse_gloo:
-                works += post_chunk(local_out, full_out, sub_offs, k, dst=0)
+                works.append(post_chunk(wire_local if wire16 else local_out, wire_full if wire16 else full_out,
+                                        sub_offs, k, dst=0))
             elif world > 1:
-                works += rehearse_chunk(k)
-        for w in works:
-            w.wait()
+                works.append(rehearse_chunk(k))
+        for k, ws in enumerate(works):
+            for w in ws:
+                w.wait()
+            if wire16 and rank == 0 and not args.rehearse_gloo:
+                finalize_received(k)
         if world > 1 and args.rehearse_gloo and rank == 0:
             for (lo, hi), t in staged:
-                full_out[lo:hi].copy_(t)
+                (wire_full if wire16 else full_out)[lo:hi].copy_(t)
             staged.clear()
+            if wire16:
+                for k in range(chunks):
+                    finalize_received(k)
 
     def fence():
         if world > 1:
@@ -289,7 +321,7 @@ def main():
             "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order"
                                    f"{', RCCL send/recv of slabs to rank 0' if world > 1 else ''})",
                        "name": args.workload, "n": n, "len": L, "measure": measure,
-                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f", {chunks} sub-slabs each, sends overlapped with compute" if world > 1 else ""),
+                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f", {chunks} sub-slabs each, sends overlapped with compute, " + ("uint16 tallies" if wire16 else "f64") + " on the wire" if world > 1 else ""),
                        "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

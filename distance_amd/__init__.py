@@ -6,7 +6,7 @@ The product is ``libdistance_hip.so`` (hand-written gfx950 HIP kernels behind th
 tests and ``bench.py``.  It never imports ``oracle`` and has no CPU compute path.
 """
 from ._lib import DistanceError, LIB_PATH, declared_symbols, load
-from .engine import (FLOAT_MEASURES, INT_MEASURES, MEASURES, Engine, finalize, format_distance,
+from .engine import (OUT_DISTANCE, OUT_TALLY, OUT_TALLY16, FLOAT_MEASURES, INT_MEASURES, MEASURES, Engine, finalize, format_distance,
                      partition_rect, partition_square, plan_tiles, square_pairs, square_row_start, tally_width)
 
 __all__ = ["DistanceError", "Engine", "MEASURES", "INT_MEASURES", "FLOAT_MEASURES", "LIB_PATH",

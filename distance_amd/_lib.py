@@ -56,6 +56,8 @@ _SIGS = {
     "dst_run_square": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t, _vp]),
     "dst_run_rect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
                                C.c_size_t, _vp]),
+    "dst_finalize_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                      _vp, _vp, C.c_size_t, _vp]),
     "dst_run_square_host": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t]),
     "dst_run_rect_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
                                     C.c_size_t]),

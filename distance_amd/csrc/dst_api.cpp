@@ -207,7 +207,7 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
         return DST_ERR_ARG;
     if (measure < DST_N || measure > DST_TN93)
         return fail(ctx, DST_ERR_ARG, "unknown measure");
-    if (out_kind != DST_OUT_DISTANCE && out_kind != DST_OUT_TALLY)
+    if (out_kind != DST_OUT_DISTANCE && out_kind != DST_OUT_TALLY && out_kind != DST_OUT_TALLY16)
         return fail(ctx, DST_ERR_ARG, "unknown output kind");
     if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
         return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
@@ -223,6 +223,8 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
     }
     if (rb > re || re > rows.n)
         return fail(ctx, DST_ERR_ARG, "row range out of bounds");
+    if (out_kind == DST_OUT_TALLY16 && rows.len > 65535)
+        return fail(ctx, DST_ERR_ARG, "DST_OUT_TALLY16 needs alignments shorter than 65,536 sites");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const uint64_t total_pairs = pairs_in_rows(square, cols.n, rb, re);
@@ -265,10 +267,12 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
     uint32_t ksplit = 1;
     if (ctx->ksplit >= 1) {
         ksplit = (uint32_t)ctx->ksplit;
-    } else if (nblocks && nblocks < 2048 && rows.nchunks >= 16) {
+    } else if (nblocks && nblocks < 2048 && rows.nchunks >= 16 && out_kind != DST_OUT_TALLY16) {
         ksplit = (uint32_t)std::min<uint64_t>({(2048 + nblocks - 1) / nblocks, rows.nchunks / 8, (uint64_t)64});
     }
     ksplit = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(ksplit, 1), std::max<size_t>(rows.nchunks, 1));
+    if (out_kind == DST_OUT_TALLY16)
+        ksplit = 1;  // no 16-bit atomics: such launches sweep L in one piece
     pl.ksplit = ksplit;
     const bool f64_out = out_kind == DST_OUT_DISTANCE && !measure_is_int(measure);
     if (nblocks && ksplit > 1) {
@@ -293,7 +297,7 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
         HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
         ctx->timed_pair = true;
         if (ksplit > 1 && f64_out)
-            HIP_TRY(ctx, launch_finalize(measure, pl, ctx->scratch, (double *)d_out, stream));
+            HIP_TRY(ctx, launch_finalize(measure, pl, ctx->scratch, false, d_out, stream));
     }
     if (!stream_v)
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -527,6 +531,53 @@ int dst_run_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t
 {
     return run_common(ctx, measure, false, row_slot, col_slot, row_begin, row_end, out_kind, d_out, cap,
                       stream);
+}
+
+int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot, uint64_t row_begin,
+                        uint64_t row_end, int tally_kind, const void *d_tallies, void *d_out, size_t cap,
+                        void *stream_v)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (measure < DST_N || measure > DST_TN93)
+        return fail(ctx, DST_ERR_ARG, "unknown measure");
+    if (tally_kind != DST_OUT_TALLY && tally_kind != DST_OUT_TALLY16)
+        return fail(ctx, DST_ERR_ARG, "tally_kind must be DST_OUT_TALLY or DST_OUT_TALLY16");
+    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    DeviceSet &rows = ctx->set[row_slot];
+    DeviceSet &cols = ctx->set[col_slot];
+    if (!rows.loaded || !cols.loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    if (row_begin > row_end || row_end > rows.n)
+        return fail(ctx, DST_ERR_ARG, "row range out of bounds");
+    const uint64_t pairs = pairs_in_rows(square != 0, cols.n, row_begin, row_end);
+    if (pairs * 8 > cap)
+        return fail(ctx, DST_ERR_CAPACITY, "output buffer too small for the requested rows");
+    if (pairs == 0)
+        return DST_OK;
+    if (!d_tallies || !d_out)
+        return fail(ctx, DST_ERR_ARG, "null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    if (measure == DST_TN93) {
+        int rc = need_counts(ctx, rows, stream);
+        if (!rc && &cols != &rows)
+            rc = need_counts(ctx, cols, stream);
+        if (rc)
+            return rc;
+    }
+    PairLaunch pl{};
+    pl.rows = &rows;
+    pl.cols = &cols;
+    pl.square = square != 0;
+    pl.row_begin = row_begin;
+    pl.row_end = row_end;
+    pl.out_base = square ? square_row_start(cols.n, row_begin) : 0;
+    HIP_TRY(ctx, launch_finalize(measure, pl, d_tallies, tally_kind == DST_OUT_TALLY16, d_out, stream));
+    if (!stream_v)
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return DST_OK;
 }
 
 int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,

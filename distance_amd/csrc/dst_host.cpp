@@ -187,6 +187,8 @@ size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs)
 {
     if (out_kind == DST_OUT_TALLY)
         return (size_t)n_pairs * (size_t)tally_width(measure) * sizeof(uint32_t);
+    if (out_kind == DST_OUT_TALLY16)
+        return (size_t)n_pairs * (size_t)tally_width(measure) * sizeof(uint16_t);
     return (size_t)n_pairs * 8;
 }
 

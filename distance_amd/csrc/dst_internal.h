@@ -61,7 +61,7 @@ struct PairLaunch {
     bool square;
     uint64_t row_begin, row_end;  // rows of `rows` this launch covers
     uint64_t out_base;            // canonical index of the first pair of this launch
-    int out_kind;                 // DST_OUT_DISTANCE (f64 / int64 by measure) or DST_OUT_TALLY
+    int out_kind;                 // DST_OUT_DISTANCE (f64 / int64 by measure), DST_OUT_TALLY or _TALLY16
     void *d_out;                  // first pair of this launch
     const BlockDesc *d_blocks;
     uint32_t nblocks;
@@ -73,8 +73,8 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
                        unsigned long long *d_first_bad, hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
-hipError_t launch_finalize(int measure, const PairLaunch &pl, const uint32_t *d_tallies, double *d_out,
-                           hipStream_t stream);
+hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,
+                           void *d_out, hipStream_t stream);
 TileShape tile_shape(int measure, int variant);
 int variant_count(int measure);
 

@@ -330,6 +330,7 @@ constexpr int OUT_TALLY = -1;      // uint32 x NT site tallies per pair
 constexpr int OUT_INT = -2;        // int64 (n / n_high)
 constexpr int OUT_TALLY_ADD = -3;  // split-L launch: atomicAdd partial tallies into a zeroed buffer
 constexpr int OUT_INT_ADD = -4;    // split-L launch: atomicAdd partial counts into zeroed int64
+constexpr int OUT_TALLY16 = -5;    // uint16 x NT per pair (alignments shorter than 65,536 sites)
 // OUT >= 0: the measure id whose f64 distance the epilogue writes
 
 template <int MEASURE>
@@ -490,6 +491,17 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
                         static_cast<int64_t *>(out_v)[at] = (int64_t)o[0];
                     } else if constexpr (OUT == OUT_INT_ADD) {
                         atomicAdd(static_cast<unsigned long long *>(out_v) + at, (unsigned long long)o[0]);
+                    } else if constexpr (OUT == OUT_TALLY16) {
+                        uint16_t *o16 = static_cast<uint16_t *>(out_v);
+                        if constexpr (NT == 2) {
+                            reinterpret_cast<uint32_t *>(o16)[at] = o[0] | (o[1] << 16);
+                        } else if constexpr (NT == 4) {
+                            reinterpret_cast<uint2 *>(o16)[at] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+                                o16[at * NT + k] = (uint16_t)o[k];
+                        }
                     } else if constexpr (OUT == OUT_TALLY_ADD) {
 #pragma unroll
                         for (int k = 0; k < NT; ++k)
@@ -546,17 +558,19 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
     }
 }
 
-// tallies -> f64 for split-L launches (their partial tallies meet in a scratch buffer first);
-// one block per row of the launch, threads stride along the row's pairs (coalesced)
-template <int MEASURE>
-__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ tallies,
+// tallies already in device memory -> the FloatInt payload (f64, or int64 for n / n_high): used
+// after split-L launches (whose partial tallies meet in a scratch buffer) and by
+// dst_finalize_device (tallies gathered from other GPUs).  One block per row of the range;
+// threads stride along the row's pairs (coalesced).  T = uint32_t or uint16_t tallies.
+template <int MEASURE, class T>
+__global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tallies,
                                                        const uint32_t *__restrict__ q_counts,
                                                        const uint32_t *__restrict__ t_counts,
-                                                       double *__restrict__ out, uint32_t n_cols,
+                                                       void *__restrict__ out_v, uint32_t n_cols,
                                                        uint32_t row_begin, uint64_t out_base,
                                                        int square)
 {
-    constexpr int NT = MEASURE == DST_K80 ? 3 : MEASURE == DST_TN93 ? 4 : 2;
+    constexpr int NT = MEASURE == DST_N_HIGH ? 1 : MEASURE == DST_K80 ? 3 : MEASURE == DST_TN93 ? 4 : 2;
     const uint32_t i = row_begin + blockIdx.x;
     const uint32_t jstart = square ? i + 1 : 0;
     if (jstart >= n_cols)
@@ -572,9 +586,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restric
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             o[t] = tallies[at * NT + t];
-        if constexpr (MEASURE == DST_TN93)
-            tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
-        out[at] = finalize_pair<MEASURE>(o, qc, tc);
+        if constexpr (MEASURE == DST_N_HIGH) {
+            static_cast<int64_t *>(out_v)[at] = (int64_t)o[0];
+        } else {
+            if constexpr (MEASURE == DST_TN93)
+                tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
+            static_cast<double *>(out_v)[at] = finalize_pair<MEASURE>(o, qc, tc);
+        }
     }
 }
 
@@ -647,6 +665,8 @@ hipError_t launch_outputs(int measure, const PairLaunch &pl, hipStream_t stream)
     }
     if (pl.out_kind == DST_OUT_TALLY)
         return launch_one<M, BM, TN, MINW, OUT_TALLY>(pl, stream);
+    if (pl.out_kind == DST_OUT_TALLY16)
+        return launch_one<M, BM, TN, MINW, OUT_TALLY16>(pl, stream);
     if constexpr (M::NT == 1) {
         return launch_one<M, BM, TN, MINW, OUT_INT>(pl, stream);
     } else if constexpr (M::NT == 2) {
@@ -723,17 +743,28 @@ hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStrea
 }
 #undef DST_CASE
 
-hipError_t launch_finalize(int measure, const PairLaunch &pl, const uint32_t *d_tallies, double *d_out,
-                           hipStream_t stream)
+hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,
+                           void *d_out, hipStream_t stream)
 {
     const unsigned rows = (unsigned)(pl.row_end - pl.row_begin);
     if (rows == 0)
         return hipSuccess;
-#define DST_FIN(MEAS)                                                                              \
-    hipLaunchKernelGGL((finalize_kernel<MEAS>), dim3(rows), dim3(256), 0, stream, d_tallies,       \
-                       pl.rows->counts, pl.cols->counts, d_out, (uint32_t)pl.cols->n,              \
-                       (uint32_t)pl.row_begin, pl.out_base, pl.square ? 1 : 0)
+#define DST_FIN(MEAS)                                                                               \
+    do {                                                                                            \
+        if (tallies16)                                                                              \
+            hipLaunchKernelGGL((finalize_kernel<MEAS, uint16_t>), dim3(rows), dim3(256), 0, stream, \
+                               static_cast<const uint16_t *>(d_tallies), pl.rows->counts,           \
+                               pl.cols->counts, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, \
+                               pl.out_base, pl.square ? 1 : 0);                                     \
+        else                                                                                        \
+            hipLaunchKernelGGL((finalize_kernel<MEAS, uint32_t>), dim3(rows), dim3(256), 0, stream, \
+                               static_cast<const uint32_t *>(d_tallies), pl.rows->counts,           \
+                               pl.cols->counts, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, \
+                               pl.out_base, pl.square ? 1 : 0);                                     \
+    } while (0)
     switch (measure) {
+    case DST_N:
+    case DST_N_HIGH: DST_FIN(DST_N_HIGH); break;
     case DST_RAW: DST_FIN(DST_RAW); break;
     case DST_JC69: DST_FIN(DST_JC69); break;
     case DST_K80: DST_FIN(DST_K80); break;

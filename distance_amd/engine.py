@@ -16,7 +16,7 @@ from ._lib import DistanceError, load
 MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
 FLOAT_MEASURES = ("raw", "jc69", "k80", "tn93")
-OUT_DISTANCE, OUT_TALLY = 0, 1
+OUT_DISTANCE, OUT_TALLY, OUT_TALLY16 = 0, 1, 2
 
 
 def _measure_id(measure) -> int:
@@ -178,17 +178,19 @@ class Engine:
     def _alloc(self, m: int, out_kind: int, pairs: int) -> np.ndarray:
         if out_kind == OUT_TALLY:
             return np.zeros((pairs, self._lib.dst_tally_width(m)), np.uint32)
+        if out_kind == OUT_TALLY16:
+            return np.zeros((pairs, self._lib.dst_tally_width(m)), np.uint16)
         return np.zeros(pairs, np.int64 if m in (0, 1) else np.float64)
 
     def run_square(self, measure, row_begin: int = 0, row_end: int | None = None,
-                   tallies: bool = False) -> np.ndarray:
+                   tallies: bool = False, tallies16: bool = False) -> np.ndarray:
         """Distances (or tallies) of pairs (i, j), row_begin <= i < row_end, j > i, canonical order."""
         m = _measure_id(measure)
         n, _ = self.set_info(0)
         row_end = n if row_end is None else row_end
         pairs = square_row_start(n, min(row_end, n)) - square_row_start(n, min(row_begin, n)) \
             if row_end > row_begin else 0
-        kind = OUT_TALLY if tallies else OUT_DISTANCE
+        kind = OUT_TALLY16 if tallies16 else OUT_TALLY if tallies else OUT_DISTANCE
         out = self._alloc(m, kind, pairs)
         self._check(self._lib.dst_run_square_host(self._h, m, row_begin, row_end, kind, out.ctypes.data,
                                                   out.nbytes))
@@ -215,10 +217,18 @@ class Engine:
 
     # ---- runs into device memory (bench / multi-GPU) ------------------------------------------
     def run_square_device(self, measure, row_begin: int, row_end: int, d_out: int, capacity: int,
-                          tallies: bool = False, stream: int | None = None):
+                          tallies: bool = False, stream: int | None = None, out_kind: int | None = None):
         m = _measure_id(measure)
-        self._check(self._lib.dst_run_square(self._h, m, row_begin, row_end,
-                                             OUT_TALLY if tallies else OUT_DISTANCE, d_out, capacity, stream))
+        kind = out_kind if out_kind is not None else (OUT_TALLY if tallies else OUT_DISTANCE)
+        self._check(self._lib.dst_run_square(self._h, m, row_begin, row_end, kind, d_out, capacity, stream))
+
+    def finalize_device(self, measure, row_begin: int, row_end: int, d_tallies: int, d_out: int, capacity: int,
+                        tally_kind: int = OUT_TALLY16, square: bool = True, row_slot: int = 0, col_slot: int = 0,
+                        stream: int | None = None):
+        """Tallies already on this GPU (OUT_TALLY / OUT_TALLY16 layout) -> distances (dst_finalize_device)."""
+        m = _measure_id(measure)
+        self._check(self._lib.dst_finalize_device(self._h, m, int(square), row_slot, col_slot, row_begin, row_end,
+                                                  tally_kind, d_tallies, d_out, capacity, stream))
 
     def run_rect_device(self, measure, row_slot: int, col_slot: int, row_begin: int, row_end: int,
                         d_out: int, capacity: int, tallies: bool = False, stream: int | None = None):

@@ -86,6 +86,7 @@ def post_chunk(local: torch.Tensor | None, full: torch.Tensor | None, pair_offse
                dst: int = 0, group=None):
     """Post (do not wait for) the exchange of sub-slab k: every rank != dst sends
     local[its chunk-k range, relative to its slab start]; dst receives each straight into `full`.
+    `local` / `full` index pairs along dim 0 (f64 / int64 results, or (pairs, width) uint16 tallies).
     On nccl the transfers run on RCCL's stream, ordered after the work already queued on the
     current stream, so the caller can go on computing sub-slab k+1.  Returns work handles."""
     rank = dist.get_rank(group)

@@ -65,8 +65,11 @@ typedef enum {
  *                      raw, jc69 : {n, d}                        (src/measures.rs:57-66)
  *                      k80       : {count_L, ts, tv}             (src/measures.rs:81-107)
  *                      tn93      : {count_L, count_d, count_P1, count_P2} (src/measures.rs:150-175)
- *                    finalise with dst_finalize() on the host for bit-identical TSV text. */
-typedef enum { DST_OUT_DISTANCE = 0, DST_OUT_TALLY = 1 } dst_output;
+ *                    finalise with dst_finalize() on the host for bit-identical TSV text.
+ *  DST_OUT_TALLY16:  the same tallies as uint16 (2 x width bytes per pair) for alignments shorter
+ *                    than 65,536 sites: the compact form sent between GPUs; dst_finalize_device()
+ *                    turns it into distances on the receiving GPU. */
+typedef enum { DST_OUT_DISTANCE = 0, DST_OUT_TALLY = 1, DST_OUT_TALLY16 = 2 } dst_output;
 
 /* ---- library ------------------------------------------------------------------------- */
 int dst_abi_version(void);
@@ -123,6 +126,14 @@ int dst_run_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_e
 int dst_run_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
                  uint64_t row_end, int out_kind, void *d_out, size_t out_capacity_bytes,
                  void *stream);
+/* Tallies (DST_OUT_TALLY or DST_OUT_TALLY16 layout, canonical order of rows [row_begin,row_end))
+ * that are already in this GPU's memory -> the DST_OUT_DISTANCE payload in d_out, with the same
+ * device arithmetic as a direct DST_OUT_DISTANCE run (bitwise the same values).  The two sets must
+ * be uploaded on this context (tn93 reads their base counts).  Multi-GPU: rank 0 finalises the
+ * compact tallies it gathered from the other ranks. */
+int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot,
+                        uint64_t row_begin, uint64_t row_end, int tally_kind, const void *d_tallies,
+                        void *d_out, size_t out_capacity_bytes, void *stream);
 /* host-buffer forms: run + copy back (h_out is ordinary or pinned host memory) */
 int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end,
                         int out_kind, void *h_out, size_t out_capacity_bytes);

@@ -205,6 +205,34 @@ def test_split_over_L_agrees_with_single_sweep(eng):
         assert np.array_equal(ref_t.astype(np.uint64), oracle_tallies_square(m, codes)), m
 
 
+def test_tally16_and_device_finalize(eng):
+    """The compact wire form: uint16 tallies + dst_finalize_device reproduce a direct run bit for bit."""
+    import torch
+    codes = random_alignment(400, 3000, 26, divergence=0.2)
+    eng.upload(0, codes)
+    n = len(codes)
+    dev = torch.device("cuda", 0)
+    for m in ALL:
+        direct = eng.run_square(m)
+        t32 = eng.run_square(m, tallies=True)
+        t16 = eng.run_square(m, tallies16=True)
+        assert t16.dtype == np.uint16 and np.array_equal(t16.astype(np.uint32), t32), m
+        for kind, host in ((da.OUT_TALLY16, t16), (da.OUT_TALLY, t32)):
+            for rb, re in ((0, n), (37, 251)):
+                lo, hi = da.square_row_start(n, rb), da.square_row_start(n, re)
+                d_t = torch.from_numpy(host[lo:hi].copy()).to(dev)
+                d_o = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+                eng.finalize_device(m, rb, re, d_t.data_ptr(), d_o.data_ptr(), d_o.numel() * 8, tally_kind=kind)
+                torch.cuda.synchronize()
+                got = d_o.cpu().numpy()
+                if m in da.INT_MEASURES:
+                    got = got.view(np.int64)
+                assert np.array_equal(got, direct[lo:hi], equal_nan=True), (m, kind, rb)
+    eng.upload(0, random_alignment(3, 70000, 27))
+    with pytest.raises(da.DistanceError):
+        eng.run_square("raw", tallies16=True)       # tallies may exceed 16 bits
+
+
 def test_rectangle_and_stream_orders(eng):
     a = random_alignment(37, 333, 31)
     b = random_alignment(21, 333, 32)
