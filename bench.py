@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--len", type=int, default=0, help="override alignment width")
     ap.add_argument("--measure", default="", help="override measure")
     ap.add_argument("--variant", type=int, default=0, help="pair-kernel tile variant")
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: sub-slabs per rank (send k overlaps compute k+1)")
+    ap.add_argument("--chunks", type=int, default=8, help="N>1: sub-slabs per rank (send k overlaps compute k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements")
     ap.add_argument("--seed", type=int, default=0xD157A2CE)
@@ -238,22 +238,35 @@ def main():
                                     full_out.data_ptr() + 8 * lo, 8 * (hi - lo), tally_kind=da.OUT_TALLY16,
                                     stream=stream)
 
+    # N>1: sub-slab launches alternate between two streams, so the draining tail of launch k
+    # overlaps the ramp-up of launch k+1 (each launch alone is only a few waves of tiles deep)
+    sub_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if world > 1 else [work_stream]
+
     def step():
         eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
         works = []
+        for s_ in sub_streams:
+            if s_ is not work_stream:
+                s_.wait_stream(work_stream)          # the pack above feeds every sub-slab
         for k in range(chunks):
             r0, r1 = sub_rows[rank][k], sub_rows[rank][k + 1]
             lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
-            if hi > lo and wire16 and rank != 0:
-                eng.run_square_device(measure, r0, r1, wire_local.data_ptr() + 2 * width * lo, 2 * width * (hi - lo),
-                                      stream=stream, out_kind=da.OUT_TALLY16)
-            elif hi > lo:
-                eng.run_square_device(measure, r0, r1, local_out.data_ptr() + 8 * lo, 8 * (hi - lo), stream=stream)
-            if world > 1 and not args.rehearse_gloo:
-                works.append(post_chunk(wire_local if wire16 else local_out, wire_full if wire16 else full_out,
-                                        sub_offs, k, dst=0))
-            elif world > 1:
-                works.append(rehearse_chunk(k))
+            ks = sub_streams[k % len(sub_streams)]
+            with torch.cuda.stream(ks):
+                if hi > lo and wire16 and rank != 0:
+                    eng.run_square_device(measure, r0, r1, wire_local.data_ptr() + 2 * width * lo,
+                                          2 * width * (hi - lo), stream=ks.cuda_stream, out_kind=da.OUT_TALLY16)
+                elif hi > lo:
+                    eng.run_square_device(measure, r0, r1, local_out.data_ptr() + 8 * lo, 8 * (hi - lo),
+                                          stream=ks.cuda_stream)
+                if world > 1 and not args.rehearse_gloo:
+                    works.append(post_chunk(wire_local if wire16 else local_out, wire_full if wire16 else full_out,
+                                            sub_offs, k, dst=0))
+                elif world > 1:
+                    works.append(rehearse_chunk(k))
+        for s_ in sub_streams:
+            if s_ is not work_stream:
+                work_stream.wait_stream(s_)          # the next step's pack must not overtake them
         for k, ws in enumerate(works):
             for w in ws:
                 w.wait()
