@@ -317,6 +317,31 @@ def test_strided_and_unaligned_rows(eng):
     assert_close(eng.run_square("raw"), want)
 
 
+def test_upload_from_device_memory_aligned_and_unaligned(eng):
+    """dst_upload_device: codes (and tn93 base counts) already in HBM, with 16-byte-aligned rows
+    (vector loads) and with an odd offset / odd stride (guarded byte path)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    codes = random_alignment(37, 1000, 72)
+    want = oracle.all_pairs_square("tn93", codes)
+    counts = oracle.count_bases_matrix(codes).astype(np.uint32)
+    d_aligned = torch.from_numpy(codes).to(dev)
+    big = torch.zeros((37, 1031), dtype=torch.uint8, device=dev)
+    big[:, 3:1003] = d_aligned
+    view = big[:, 3:1003]                                  # offset 3, stride 1031
+    d_counts = torch.from_numpy(counts).to(dev)
+    for t_, cnt in ((d_aligned, None), (view, None), (view, d_counts)):
+        assert t_.stride(1) == 1
+        eng.upload_device(0, t_.data_ptr(), 37, 1000, t_.stride(0), None if cnt is None else cnt.data_ptr())
+        assert_close(eng.run_square("tn93"), want)
+        assert np.array_equal(eng.base_counts(0), counts)
+    bad = view.clone()
+    bad[5, 999] = 7
+    with pytest.raises(da.DistanceError) as ei:
+        eng.upload_device(0, bad.data_ptr(), 37, 1000, bad.stride(0))
+    assert "record 5 at site 999" in ei.value.message
+
+
 def test_large_shape_properties(eng):
     """BASELINE-sized rows (L = 30,000) on a few thousand records: size-independent properties
     plus a sampled oracle check."""
