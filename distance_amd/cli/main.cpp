@@ -637,7 +637,12 @@ int main(int argc, char **argv)
     } else {
         // ---- stream(): src/lib.rs:269-365; stream_fasta(): src/fastaio.rs:215-286 ---------------
         const Alignment &ref = loaded[0];
-        const size_t batch_records = std::max<size_t>(1, std::min<size_t>(4096, a.slab_pairs / std::max<size_t>(ref.n, 1)));
+        // a streamed batch is bounded by records (4096), by result pairs (--slab-pairs) and by bytes
+        // (512 MiB of codes: C4-sized 5 Mbp records come ~100 at a time; split-L launches keep the GPU
+        // busy on such short batches)
+        const size_t by_bytes = ((size_t)512 << 20) / std::max<size_t>(ref.width, 1);
+        const size_t batch_records =
+            std::max<size_t>(1, std::min<size_t>({(size_t)4096, a.slab_pairs / std::max<size_t>(ref.n, 1), by_bytes}));
         // reader thread: parse + encode batch k+1 while the GPUs and the formatting pool work on
         // batch k (the reference's stream_fasta thread + bounded channel, src/lib.rs:272, 290-307)
         std::mutex qmu;

@@ -7,14 +7,17 @@
 //                    and, fused in its epilogue, tallies -> f64 distance in the reference's
 //                    operation order              (src/measures.rs:68, 76, 109-112, 118-190)
 //
-// Design (DESIGN.md has the numbers): integer / bitwise work, no MFMA.  One pair costs 5..10
-// VALU ops per 32 sites.  A block owns BM "row" records x 256*TN "column" records.  Each lane
-// owns TN column records and keeps their plane words in VGPRs; the row records are wave-uniform,
-// so their plane words arrive through SCALAR loads (s_load_dwordx4.. via the scalar cache) and
-// feed the VALU as SGPR operands: no LDS traffic, no barriers, accumulators live in VGPRs for the
-// whole sweep over L, and every VALU slot does site work (v_and_b32 / v_and_or_b32 /
-// v_bcnt_u32_b32).  Tiles of one column panel are dealt to workgroups that share an XCD so the
-// panel streams from HBM once per XCD and is then served by that XCD's L2.
+//   finalize_kernel  tallies already in HBM -> distances (split-L launches, dst_finalize_device)
+//
+// Design (DESIGN.md has the numbers): integer / bitwise work, no MFMA.  One pair costs 5..8 VALU
+// ops per 32 sites (v_and_b32, v_bitop3_b32, v_bcnt_u32_b32).  A block owns BM "row" records x
+// 256*TN "column" records.  Each lane owns TN column records and keeps their plane words of the
+// current 128-site chunk in VGPRs; the BM row records of the tile are wave-uniform and come from
+// a small double-buffered LDS tile by broadcast ds_read_b128 — NOT through scalar loads: on gfx950
+// a VALU op with an SGPR operand issues at half rate (tools/ubench/valu_rate.hip).  Tallies live
+// in VGPRs for the whole sweep over L.  Tiles of one column panel are dealt to workgroups that
+// share an XCD so the panel is served by that XCD's L2.  The kernel runs at the measured issue
+// ceiling of its instruction mix (tools/ubench/ifetch.hip, order.hip).
 #include "dst_internal.h"
 
 namespace dst {
