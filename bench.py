@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 import distance_amd as da
-from distance_amd.multi import chunked_layout, post_chunk, slab_layout
+from distance_amd.multi import chunked_layout, post_chunk, root_share, slab_layout
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
 HBM_COPY_GBS = 6290.0
@@ -181,19 +181,25 @@ def main():
     eng = da.Engine(dev_index)
     eng.set_variant(args.variant)
 
-    bounds, offsets = slab_layout(n, world, square=True)
+    # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
+    # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
+    # same device arithmetic as a direct run).  k80 (6 B) / tn93 (8 B) travel as f64.
+    width = da.tally_width(measure)
+    wire16 = world > 1 and L < 65536 and 2 * width < 8 and not args.wire_f64
+    # rank 0 also finalises every pair it receives (HBM-bound: 2*width B read + 8 B written at
+    # ~4.5 TB/s) — it gets a correspondingly smaller share of the pair space
+    first_share = None
+    if wire16:
+        pair_rate = {"raw": 6.3e9, "jc69": 6.3e9, "n": 9.5e9, "n_high": 9.5e9}[measure] * 30000.0 / max(L, 1)
+        first_share = root_share(world, (2 * width + 8) / 4.5e12 * pair_rate)
+    bounds, offsets = slab_layout(n, world, square=True, first_share=first_share)
     rb, re = bounds[rank], bounds[rank + 1]
     my_pairs = offsets[rank + 1] - offsets[rank]
     out_dtype = torch.int64 if measure in da.INT_MEASURES else torch.float64
     # N>1: each rank's range is cut into sub-slabs; sub-slab k is on its way to rank 0 (RCCL
     # send/recv on RCCL's own stream) while sub-slab k+1 is being computed.
     chunks = args.chunks if world > 1 else 1
-    sub_rows, sub_offs = chunked_layout(n, world, chunks)
-    # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
-    # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
-    # same device arithmetic as a direct run).  k80 (6 B) / tn93 (8 B) travel as f64.
-    width = da.tally_width(measure)
-    wire16 = world > 1 and L < 65536 and 2 * width < 8 and not args.wire_f64
+    sub_rows, sub_offs = chunked_layout(n, world, chunks, first_share=first_share)
     if world == 1:
         full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
         local_out = full_out
@@ -334,7 +340,7 @@ def main():
             "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order"
                                    f"{', RCCL send/recv of slabs to rank 0' if world > 1 else ''})",
                        "name": args.workload, "n": n, "len": L, "measure": measure,
-                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f", {chunks} sub-slabs each, sends overlapped with compute, " + ("uint16 tallies" if wire16 else "f64") + " on the wire" if world > 1 else ""),
+                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f" (rank 0: {first_share:.4f} of the pairs, it also finalises the gathered tallies)" if first_share else "") + (f", {chunks} sub-slabs each, sends overlapped with compute, " + ("uint16 tallies" if wire16 else "f64") + " on the wire" if world > 1 else ""),
                        "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

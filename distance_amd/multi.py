@@ -13,12 +13,45 @@ import torch.distributed as dist
 from .engine import partition_rect, partition_square, square_row_start
 
 
-def slab_layout(n: int, world: int, square: bool = True, n_cols: int | None = None):
+def _row_at(n: int, target: int, lo: int = 0) -> int:
+    """First row >= lo whose first canonical pair index reaches `target` (square order)."""
+    a, b = lo, n
+    while a < b:
+        mid = (a + b) // 2
+        if square_row_start(n, mid) < target:
+            a = mid + 1
+        else:
+            b = mid
+    return a
+
+
+def root_share(world: int, root_cost_per_received_pair: float) -> float:
+    """Fraction of the pairs rank 0 should compute so that every rank finishes together when rank 0
+    also spends `root_cost_per_received_pair` (in units of one pair's compute time) on every pair it
+    receives (finalising gathered tallies).  0 cost -> 1/world."""
+    if world <= 1:
+        return 1.0
+    r, w1 = float(root_cost_per_received_pair), 1.0 / (world - 1)
+    return max(0.0, min(1.0 / world, (w1 - r) / ((1.0 - r) + w1)))
+
+
+def slab_layout(n: int, world: int, square: bool = True, n_cols: int | None = None,
+                first_share: float | None = None):
     """Row bounds and canonical pair offsets of each rank's slab.
 
     Returns (bounds, offsets): rank r owns rows [bounds[r], bounds[r+1]) and canonical pair
-    indices [offsets[r], offsets[r+1])."""
-    if square:
+    indices [offsets[r], offsets[r+1]).  `first_share` (square only): fraction of all pairs given
+    to rank 0, the rest split evenly (see root_share)."""
+    if square and first_share is not None and world > 1:
+        total = n * (n - 1) // 2
+        p0 = int(total * first_share)
+        bounds = [0]
+        for r in range(1, world):
+            target = p0 + (total - p0) * (r - 1) // (world - 1)
+            bounds.append(_row_at(n, target, bounds[-1]))
+        bounds.append(n)
+        offsets = [square_row_start(n, b) for b in bounds]
+    elif square:
         bounds = partition_square(n, world)
         offsets = [square_row_start(n, b) for b in bounds]
     else:
@@ -55,27 +88,19 @@ def gather_slabs(local: torch.Tensor, offsets: list[int], full: torch.Tensor | N
     return ops
 
 
-def chunked_layout(n: int, world: int, chunks: int):
+def chunked_layout(n: int, world: int, chunks: int, first_share: float | None = None):
     """Every rank's row range cut again into `chunks` sub-ranges of near-equal pair count, so a
     rank can send sub-slab k while it computes sub-slab k+1.
 
     Returns (row_bounds, pair_offsets): row_bounds[r][k] .. row_bounds[r][k+1] are the rows of
     rank r's k-th sub-slab and pair_offsets[r][k] its first canonical pair index."""
-    bounds, _ = slab_layout(n, world, square=True)
+    bounds, _ = slab_layout(n, world, square=True, first_share=first_share)
     row_bounds, pair_offsets = [], []
     for r in range(world):
         lo, hi = square_row_start(n, bounds[r]), square_row_start(n, bounds[r + 1])
         rows = [bounds[r]]
         for k in range(1, chunks):
-            target = lo + (hi - lo) * k // chunks
-            a, b = rows[-1], bounds[r + 1]
-            while a < b:                      # first row whose start index reaches the target
-                mid = (a + b) // 2
-                if square_row_start(n, mid) < target:
-                    a = mid + 1
-                else:
-                    b = mid
-            rows.append(a)
+            rows.append(min(_row_at(n, lo + (hi - lo) * k // chunks, rows[-1]), bounds[r + 1]))
         rows.append(bounds[r + 1])
         row_bounds.append(rows)
         pair_offsets.append([square_row_start(n, x) for x in rows])

@@ -114,3 +114,21 @@ def test_chunked_layout_is_a_refinement_of_the_rank_partition():
         assert all(a <= b for a, b in zip(rows[r], rows[r][1:]))
         sizes = [offs[r][k + 1] - offs[r][k] for k in range(chunks)]
         assert max(sizes) - min(sizes) <= 2 * n
+
+
+def test_root_share_balances_the_root_finalisation():
+    from distance_amd.multi import chunked_layout, root_share, slab_layout
+    assert root_share(8, 0.0) == pytest.approx(1 / 8)
+    assert root_share(1, 0.5) == 1.0
+    n, world, r = 50000, 8, 0.017
+    f0 = root_share(world, r)
+    assert 0.10 < f0 < 0.125
+    bounds, offs = slab_layout(n, world, first_share=f0)
+    total = offs[-1]
+    mine = [offs[k + 1] - offs[k] for k in range(world)]
+    assert sum(mine) == total == n * (n - 1) // 2 and bounds[0] == 0 and bounds[-1] == n
+    t_root = mine[0] + r * (total - mine[0])
+    for k in range(1, world):
+        assert abs(mine[k] - t_root) / t_root < 0.01      # everybody finishes together
+    rows, o2 = chunked_layout(n, world, 8, first_share=f0)
+    assert [x[0] for x in rows] == bounds[:-1] and [x[-1] for x in rows] == bounds[1:]
