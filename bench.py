@@ -200,6 +200,7 @@ def main():
     # send/recv on RCCL's own stream) while sub-slab k+1 is being computed.
     chunks = args.chunks if world > 1 else 1
     sub_rows, sub_offs = chunked_layout(n, world, chunks, first_share=first_share)
+    # (the uint16 tallies travel as raw bytes: NCCL/RCCL has no 16-bit unsigned type)
     if world == 1:
         full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
         local_out = full_out
@@ -208,11 +209,11 @@ def main():
         full_out = torch.empty(total_pairs, dtype=out_dtype, device=dev)
         local_out = full_out[offsets[0]:offsets[1]]          # rank 0 computes straight into place
         wire_local = None
-        wire_full = torch.empty((total_pairs, width), dtype=torch.uint16, device=dev) if wire16 else None
+        wire_full = torch.empty((total_pairs, 2 * width), dtype=torch.uint8, device=dev) if wire16 else None
     else:
         full_out = None
         local_out = None if wire16 else torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
-        wire_local = torch.empty((max(my_pairs, 1), width), dtype=torch.uint16, device=dev) if wire16 else None
+        wire_local = torch.empty((max(my_pairs, 1), 2 * width), dtype=torch.uint8, device=dev) if wire16 else None
         wire_full = None
     base = offsets[rank]
 
@@ -226,7 +227,7 @@ def main():
             for r in range(1, world):
                 lo, hi = sub_offs[r][k], sub_offs[r][k + 1]
                 if hi > lo:
-                    t = torch.empty((hi - lo, width), dtype=torch.uint16) if wire16 else torch.empty(hi - lo, dtype=out_dtype)
+                    t = torch.empty((hi - lo, 2 * width), dtype=torch.uint8) if wire16 else torch.empty(hi - lo, dtype=out_dtype)
                     staged.append(((lo, hi), t))
                     host.append(dist.P2POp(dist.irecv, t, r))
             return dist.batch_isend_irecv(host) if host else []
