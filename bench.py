@@ -43,6 +43,9 @@ WORKLOADS = {
     "C5": (200_000, 1_000, "jc69"),
 }
 OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  # VALU ops / 32 sites
+# Measured issue ceiling of the raw step (1 v_and + 4 v_bitop3 + 2 v_bcnt on VGPRs only, 8 waves/SIMD,
+# no memory traffic): tools/ubench/ifetch.hip / order.hip, profiles/r01/ubench_rawstep.txt
+RAW_STEP_CEILING_NS = 10.6
 
 
 def synth_alignment(n: int, L: int, seed: int, device) -> torch.Tensor:
@@ -354,7 +357,12 @@ def main():
                                  "this exceeds physical HBM traffic (profiles/ has FETCH_SIZE); the true limiter "
                                  "is VALU issue"},
             "valu": {"achieved_lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                     "frac": lane_ops / VALU_PEAK_LANE_OPS, "ops_per_32_sites": OPS_PER_WORD[measure]},
+                     "frac": lane_ops / VALU_PEAK_LANE_OPS, "ops_per_32_sites": OPS_PER_WORD[measure],
+                     "ns_per_32site_step_per_simd": k_ms * 1e6 / (launch_pairs * words / 65536.0),
+                     "measured_issue_ceiling_ns": RAW_STEP_CEILING_NS if measure in ("raw", "jc69") else None,
+                     "note": "v_bcnt_u32_b32 issues at half rate on gfx950, so the nominal full-rate peak is not "
+                             "reachable by this instruction mix; the ceiling is a pure-register microbenchmark "
+                             "of the same 7 instructions"},
             "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms, "finalize": float(np.mean(fin_ms))},
             "site_compares_per_s": value * L,
         }
