@@ -17,6 +17,7 @@ _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
 _u64p = C.POINTER(C.c_uint64)
 _vp = C.c_void_p
+SLAB_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
 
 
 class DistanceError(RuntimeError):
@@ -61,6 +62,7 @@ _SIGS = {
     "dst_run_square_host": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t]),
     "dst_run_rect_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
                                     C.c_size_t]),
+    "dst_run_slabs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
     "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),
     "dst_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "dst_plan_tiles": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp,

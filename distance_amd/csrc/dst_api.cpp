@@ -580,6 +580,102 @@ int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int
     return DST_OK;
 }
 
+int dst_run_slabs(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot, int out_kind,
+                  uint64_t max_pairs, dst_slab_sink sink, void *user)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (!sink || max_pairs == 0)
+        return fail(ctx, DST_ERR_ARG, "null sink or max_pairs == 0");
+    if (square) {
+        row_slot = 0;
+        col_slot = 0;
+    }
+    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    if (!ctx->set[row_slot].loaded || !ctx->set[col_slot].loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    const uint64_t n_rows = ctx->set[row_slot].n, n_cols = ctx->set[col_slot].n;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // two device + two pinned host buffers sized for the largest slab
+    struct Slab {
+        uint64_t rb, re, first, pairs;
+    };
+    std::vector<Slab> slabs;
+    uint64_t first = 0, biggest = 0;
+    for (uint64_t rb = 0; rb < n_rows;) {
+        uint64_t re = rb, pairs = 0;
+        while (re < n_rows) {
+            const uint64_t row_pairs = square ? (n_cols - re - 1) : n_cols;
+            if (re > rb && pairs + row_pairs > max_pairs)
+                break;
+            pairs += row_pairs;
+            ++re;
+        }
+        if (pairs)
+            slabs.push_back({rb, re, first, pairs});
+        first += pairs;
+        biggest = std::max(biggest, pairs);
+        rb = re;
+    }
+    if (slabs.empty())
+        return DST_OK;
+    const size_t bytes = dst_out_bytes(measure, out_kind, biggest);
+    void *d_buf[2] = {nullptr, nullptr}, *h_buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = DST_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int k = 0; k < 2; ++k) {
+            if (d_buf[k])
+                (void)hipFree(d_buf[k]);
+            if (h_buf[k])
+                (void)hipHostFree(h_buf[k]);
+            if (done[k])
+                (void)hipEventDestroy(done[k]);
+        }
+    };
+#define SLAB_TRY(call)                                   \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) {                          \
+            rc = fail_hip(ctx, e_, #call);               \
+            cleanup();                                   \
+            return rc;                                   \
+        }                                                \
+    } while (0)
+    for (int k = 0; k < 2; ++k) {
+        SLAB_TRY(hipMalloc(&d_buf[k], bytes));
+        SLAB_TRY(hipHostMalloc(&h_buf[k], bytes, hipHostMallocDefault));
+        SLAB_TRY(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    }
+    auto issue = [&](size_t k) -> int {  // compute slab k and start its copy back, all on ctx->stream
+        const Slab &s = slabs[k];
+        const size_t nb = dst_out_bytes(measure, out_kind, s.pairs);
+        int r = run_common(ctx, measure, square != 0, row_slot, col_slot, s.rb, s.re, out_kind, d_buf[k & 1], nb,
+                           (void *)ctx->stream);
+        if (r)
+            return r;
+        hipError_t e = hipMemcpyAsync(h_buf[k & 1], d_buf[k & 1], nb, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipEventRecord(done[k & 1], ctx->stream);
+        return e == hipSuccess ? DST_OK : fail_hip(ctx, e, "copy back");
+    };
+    rc = issue(0);
+    for (size_t k = 0; rc == DST_OK && k < slabs.size(); ++k) {
+        if (k + 1 < slabs.size())
+            rc = issue(k + 1);  // the other buffer pair: slab k-1's sink call has returned
+        if (rc)
+            break;
+        SLAB_TRY(hipEventSynchronize(done[k & 1]));
+        if (sink(user, slabs[k].first, slabs[k].pairs, slabs[k].rb, slabs[k].re, h_buf[k & 1]) != 0)
+            rc = fail(ctx, DST_ERR_STATE, "stopped by sink");
+    }
+#undef SLAB_TRY
+    cleanup();
+    return rc;
+}
+
 int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,
                         void *h_out, size_t cap)
 {

@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import DistanceError, load
+from ._lib import SLAB_SINK, DistanceError, load
 
 MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
@@ -214,6 +214,25 @@ class Engine:
         [streamed record][loaded record], i.e. the reference's streamed-major output order."""
         self.upload(1, batch_codes, batch_counts)
         return self.run_rect(measure, row_slot=1, col_slot=0, tallies=tallies)
+
+    def run_slabs(self, measure, sink, max_pairs: int, square: bool = True, row_slot: int = 0, col_slot: int = 1,
+                  tallies: bool = False):
+        """In-order slab sink (dst_run_slabs): sink(first_pair, rb, re, array) per slab; a truthy return stops."""
+        m = _measure_id(measure)
+        kind = OUT_TALLY if tallies else OUT_DISTANCE
+        width = self._lib.dst_tally_width(m)
+
+        def _cb(_user, first, n_pairs, rb, re, data):
+            if tallies:
+                arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint32)), shape=(n_pairs, width))
+            elif m in (0, 1):
+                arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_int64)), shape=(n_pairs,))
+            else:
+                arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_double)), shape=(n_pairs,))
+            return 1 if sink(int(first), int(rb), int(re), arr) else 0
+
+        cb = SLAB_SINK(_cb)
+        self._check(self._lib.dst_run_slabs(self._h, m, int(square), row_slot, col_slot, kind, max_pairs, cb, None))
 
     # ---- runs into device memory (bench / multi-GPU) ------------------------------------------
     def run_square_device(self, measure, row_begin: int, row_end: int, d_out: int, capacity: int,

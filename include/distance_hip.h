@@ -139,6 +139,17 @@ int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t 
                         int out_kind, void *h_out, size_t out_capacity_bytes);
 int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
                       uint64_t row_end, int out_kind, void *h_out, size_t out_capacity_bytes);
+/* In-order sink (the shape of gather_write's input, src/lib.rs:612-644): the run is cut into row
+ * slabs of at most max_pairs pairs (>= one row each) and `sink` is called once per slab, strictly
+ * in canonical order, on the calling thread, with the slab's results in library-owned pinned host
+ * memory that is valid only during the call.  While the sink works on slab k the GPU already computes
+ * slab k+1 and its copy back is in flight.  A non-zero return from the sink stops the run
+ * (DST_ERR_STATE, message "stopped by sink").  square != 0: slot 0 against itself (row_slot/col_slot
+ * ignored). */
+typedef int (*dst_slab_sink)(void *user, uint64_t first_pair, uint64_t n_pairs, uint64_t row_begin,
+                             uint64_t row_end, const void *data);
+int dst_run_slabs(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot, int out_kind,
+                  uint64_t max_pairs, dst_slab_sink sink, void *user);
 /* bytes a run writes */
 size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs);
 /* milliseconds of the pair kernel of the most recent run and of the pack kernel of the most recent

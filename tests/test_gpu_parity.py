@@ -233,6 +233,35 @@ def test_tally16_and_device_finalize(eng):
         eng.run_square("raw", tallies16=True)       # tallies may exceed 16 bits
 
 
+def test_in_order_slab_sink(eng):
+    """dst_run_slabs: slabs arrive strictly in canonical order and concatenate to the full result."""
+    a = random_alignment(150, 400, 33)
+    b = random_alignment(40, 400, 34)
+    eng.upload(0, a)
+    eng.upload(1, b)
+    for m in ("n_high", "raw", "tn93"):
+        full = eng.run_square(m)
+        for max_pairs in (1, 97, 1000, 10**9):
+            got, firsts = [], []
+
+            def sink(first, rb, re, arr):
+                assert first == da.square_row_start(150, rb) and len(arr) == da.square_row_start(150, re) - first
+                firsts.append(first)
+                got.append(arr.copy())
+
+            eng.run_slabs(m, sink, max_pairs)
+            assert firsts == sorted(firsts)
+            assert np.array_equal(np.concatenate(got), full, equal_nan=True), (m, max_pairs)
+        rect = eng.run_rect(m, tallies=True)
+        got = []
+        eng.run_slabs(m, lambda f, rb, re, arr: got.append(arr.copy()), 333, square=False, tallies=True)
+        assert np.array_equal(np.concatenate(got).reshape(rect.shape), rect)
+    seen = []
+    with pytest.raises(da.DistanceError) as ei:
+        eng.run_slabs("raw", lambda f, rb, re, arr: seen.append(f) or len(seen) >= 2, 500)
+    assert "stopped by sink" in ei.value.message and len(seen) == 2
+
+
 def test_rectangle_and_stream_orders(eng):
     a = random_alignment(37, 333, 31)
     b = random_alignment(21, 333, 32)
