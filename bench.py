@@ -186,14 +186,14 @@ def main():
 
     # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
     # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
-    # same device arithmetic as a direct run).  k80 (6 B) / tn93 (8 B) travel as f64.
+    # same device arithmetic as a direct run); k80: 6 B.  tn93 (4 tallies = 8 B) travels as f64.
     width = da.tally_width(measure)
     wire16 = world > 1 and L < 65536 and 2 * width < 8 and not args.wire_f64
     # rank 0 also finalises every pair it receives (HBM-bound: 2*width B read + 8 B written at
     # ~4.5 TB/s) — it gets a correspondingly smaller share of the pair space
     first_share = None
     if wire16:
-        pair_rate = {"raw": 6.3e9, "jc69": 6.3e9, "n": 9.5e9, "n_high": 9.5e9}[measure] * 30000.0 / max(L, 1)
+        pair_rate = {"raw": 6.3e9, "jc69": 6.3e9, "k80": 5.5e9, "n": 9.5e9, "n_high": 9.5e9}[measure] * 30000.0 / max(L, 1)
         first_share = root_share(world, (2 * width + 8) / 4.5e12 * pair_rate)
     bounds, offsets = slab_layout(n, world, square=True, first_share=first_share)
     rb, re = bounds[rank], bounds[rank + 1]

@@ -36,6 +36,8 @@ struct dst_ctx {
     int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
     uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
     size_t scratch_bytes = 0;
+    hipEvent_t scratch_free = nullptr;  // recorded after the last reader of `scratch`
+    bool scratch_used = false;
     hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;
@@ -150,6 +152,9 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     if (s.have_counts)
         return DST_OK;
     HIP_TRY(ctx, launch_fill_counts(s, stream));
+    // complete before anyone is told the counts exist: later runs may be queued on OTHER streams
+    // (multi-GPU sub-slabs alternate between two) and would not be ordered after this kernel
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
     s.have_counts = true;
     return DST_OK;
 }
@@ -267,7 +272,7 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
     uint32_t ksplit = 1;
     if (ctx->ksplit >= 1) {
         ksplit = (uint32_t)ctx->ksplit;
-    } else if (nblocks && nblocks < 2048 && rows.nchunks >= 16 && out_kind != DST_OUT_TALLY16) {
+    } else if (nblocks && nblocks < 1024 && rows.nchunks >= 16 && out_kind != DST_OUT_TALLY16) {
         ksplit = (uint32_t)std::min<uint64_t>({(2048 + nblocks - 1) / nblocks, rows.nchunks / 8, (uint64_t)64});
     }
     ksplit = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(ksplit, 1), std::max<size_t>(rows.nchunks, 1));
@@ -279,11 +284,14 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
         if (f64_out) {
             const size_t want = (size_t)total_pairs * tally_width(measure) * sizeof(uint32_t);
             if (ctx->scratch_bytes < want) {
-                HIP_TRY(ctx, hipStreamSynchronize(stream));  // an earlier run may still read the old one
+                HIP_TRY(ctx, hipDeviceSynchronize());  // an earlier run (any stream) may still read the old one
                 rc = ensure_bytes(ctx, (void **)&ctx->scratch, &ctx->scratch_bytes, want);
                 if (rc)
                     return rc;
             }
+            // one meeting buffer per context: a run on another stream must be done with it first
+            if (ctx->scratch_used)
+                HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->scratch_free, 0));
             HIP_TRY(ctx, hipMemsetAsync(ctx->scratch, 0, want, stream));
             pl.out_kind = DST_OUT_TALLY;
             pl.d_out = ctx->scratch;
@@ -296,8 +304,11 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
         HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
         ctx->timed_pair = true;
-        if (ksplit > 1 && f64_out)
+        if (ksplit > 1 && f64_out) {
             HIP_TRY(ctx, launch_finalize(measure, pl, ctx->scratch, false, d_out, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->scratch_free, stream));
+            ctx->scratch_used = true;
+        }
     }
     if (!stream_v)
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -393,6 +404,8 @@ int dst_create(int device, dst_ctx **out)
             return bail(c, e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c->d_first_bad, sizeof(unsigned long long))) != hipSuccess)
         return bail(c, e, "hipMalloc");
+    if ((e = hipEventCreateWithFlags(&c->scratch_free, hipEventDisableTiming)) != hipSuccess)
+        return bail(c, e, "hipEventCreate");
     *out = c;
     return DST_OK;
 }
@@ -412,6 +425,8 @@ int dst_destroy(dst_ctx *ctx)
             (void)hipFree(s.d_blocks);
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
+    if (ctx->scratch_free)
+        (void)hipEventDestroy(ctx->scratch_free);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
     for (auto &ev : ctx->ev)

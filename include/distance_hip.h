@@ -88,7 +88,7 @@ int dst_set_variant(dst_ctx *ctx, int variant);
 int dst_variant_count(int measure);
 /* split-L factor: launches with few tiles and a long alignment (small sets, streamed batches) cut
  * the sweep over L into `ksplit` parts whose partial integer tallies are combined with atomics
- * (exact).  0 = automatic (default), 1 = never split, k > 1 = force. */
+ * (exact).  0 = automatic (default: launches with fewer than 1,024 tiles), 1 = never split, k > 1 = force. */
 int dst_set_ksplit(dst_ctx *ctx, int ksplit);
 
 /* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */
