@@ -7,7 +7,7 @@
 // (src/lib.rs:612-644).  The pair generators and worker pools (src/lib.rs:269-474, 502-596) are
 // replaced by libdistance_hip.so through its C ABI; -t sizes the host formatting pool and -b is
 // accepted — neither changes the output, as in the reference (src/lib.rs:919-1154).
-// Extra flags: --gpus N (default 1), --slab-pairs P (result slab size).
+// Extra flags: --gpus N (default 1) / --devices LIST, --slab-pairs P (result slab size).
 //
 // Exactness: the GPU returns integer site tallies; f64 finalisation is dst_finalize() on the host
 // (reference operation order, glibc log/sqrt), so the printed digits do not depend on the device.
@@ -86,6 +86,7 @@ void print_help()
         "  -b, --batchsize <batchsize>  Try setting this >(>) 1 to tune the workload per thread [default: 1]\n"
         "  -l, --licenses               Print licence information and exit\n"
         "      --gpus <n>               MI355X GPUs to use (default 1)\n"
+        "      --devices <list>         Explicit device ordinals, e.g. 0,1,2,3 (overrides --gpus)\n"
         "  -h, --help                   Print help\n"
         "  -V, --version                Print version");
 }
@@ -98,6 +99,7 @@ struct Args {
     bool has_output = false, has_threads = false, licenses = false;
     size_t threads = 0, batchsize = 1;
     int gpus = 1;
+    std::vector<int> devices;  // explicit device ordinals (--devices 0,1,..); empty: 0..gpus-1
     size_t slab_pairs = (size_t)1 << 24;
     std::string selftest;
 };
@@ -172,6 +174,13 @@ Args parse_args(int argc, char **argv)
             a.batchsize = parse_usize(value_of(k, arg, "--batchsize <batchsize>"), "--batchsize <batchsize>");
         } else if (arg == "--gpus" || arg.rfind("--gpus=", 0) == 0) {
             a.gpus = (int)parse_usize(value_of(k, arg, "--gpus <n>"), "--gpus <n>");
+        } else if (arg == "--devices" || arg.rfind("--devices=", 0) == 0) {
+            std::string v = value_of(k, arg, "--devices <list>");
+            for (size_t p = 0; p <= v.size();) {
+                const size_t q = std::min(v.find(',', p), v.size());
+                a.devices.push_back((int)parse_usize(v.substr(p, q - p), "--devices <list>"));
+                p = q + 1;
+            }
         } else if (arg == "--slab-pairs" || arg.rfind("--slab-pairs=", 0) == 0) {
             a.slab_pairs = std::max<size_t>(1, parse_usize(value_of(k, arg, "--slab-pairs <p>"), "--slab-pairs <p>"));
         } else if (arg == "--host-selftest") {
@@ -599,10 +608,15 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "Error: Gpu(\"no MI355X / HIP device visible: this build has no CPU path\")\n");
         return 1;
     }
-    const int G = std::max(1, std::min(a.gpus, ndev));
+    // one context (and one worker thread) per listed device; a device may be listed more than once
+    std::vector<int> devices = a.devices;
+    if (devices.empty())
+        for (int g = 0; g < std::max(1, std::min(a.gpus, ndev)); ++g)
+            devices.push_back(g);
+    const int G = (int)devices.size();
     std::vector<Ctx> gpus(G);
     for (int g = 0; g < G; ++g) {
-        if (dst_create(g, &gpus[g].h) != DST_OK) {
+        if (dst_create(devices[g], &gpus[g].h) != DST_OK) {
             std::fprintf(stderr, "Error: Gpu(\"%s\")\n", dst_last_error(nullptr));
             return 1;
         }

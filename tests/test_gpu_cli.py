@@ -91,6 +91,24 @@ def test_square_matches_oracle_text(tmp_path, measure):
     assert cli(["-m", measure], stdin=f.read_bytes()) == want      # stdin when no input is named
 
 
+def test_several_contexts_keep_canonical_order(tmp_path):
+    """The multi-GPU slab pipeline (slab k on context k mod G, ordered writer), exercised with
+    three contexts on the one GPU of the test box."""
+    codes = random_alignment(120, 300, seed=8)
+    ids = [f"r{i}" for i in range(len(codes))]
+    fa = tmp_path / "a.fasta"
+    write_fasta(fa, ids, to_text(codes))
+    for m in ("n", "tn93"):
+        want = expected_square(m, ids, codes)
+        assert cli(["-m", m, str(fa), "--devices", "0,0,0", "--slab-pairs", "500", "-t", "4"]) == want
+    b = random_alignment(50, 300, seed=9)
+    idb = [f"q{i}" for i in range(len(b))]
+    fb = tmp_path / "b.fasta"
+    write_fasta(fb, idb, to_text(b))
+    one = cli(["-m", "k80", "-i", str(fa), "-s", str(fb)])
+    assert cli(["-m", "k80", "-i", str(fa), "-s", str(fb), "--devices", "0,0", "--slab-pairs", "700"]) == one
+
+
 def test_default_measure_is_raw(tmp_path):
     codes = random_alignment(9, 100, seed=5)
     ids = [f"s{i}" for i in range(9)]
