@@ -440,3 +440,29 @@ def test_many_records_short_alignment(eng):
         j = int(rng.integers(i + 1, n))
         at = da.square_row_start(n, i) + j - i - 1
         assert list(tl[at]) == list(oracle.tallies("raw", codes[i], codes[j]))
+
+
+def test_two_hundred_thousand_records(eng):
+    """C5-sized record count (200,000 x 1,000): rows past 16 bits, 391 column panels, 64-bit canonical
+    offsets; sampled rows of the square run against the oracle."""
+    n, L = 200_000, 1000
+    rng = np.random.default_rng(17)
+    root = rng.choice(np.array([136, 72, 40, 24], np.uint8), size=L)
+    codes = np.tile(root, (n, 1))
+    mut = rng.random((n, L)) < 2e-3
+    codes[mut] = rng.choice(CODES, size=int(mut.sum()))
+    eng.upload(0, codes)
+    for i in (0, 65535, 65536, 131071, 199998, int(rng.integers(0, n - 1))):
+        got = eng.run_square("jc69", i, i + 1)
+        assert len(got) == n - i - 1
+        tl = eng.run_square("jc69", i, i + 1, tallies=True)
+        js = sorted(set([i + 1, n - 1] + [int(x) for x in rng.integers(i + 1, n, 25)]))
+        for j in js:
+            want = oracle.pair_distance("jc69", codes[i], codes[j])
+            g = got[j - i - 1]
+            assert (math.isnan(g) and math.isnan(want)) or abs(g - want) <= TOL, (i, j)
+            assert list(tl[j - i - 1]) == list(oracle.tallies("raw", codes[i], codes[j]))
+    # the last rows of the triangle in one call: canonical offsets near n(n-1)/2 = 2e10
+    tail = eng.run_square("n_high", n - 3, n)
+    want = [oracle.pair_distance("n_high", codes[a], codes[b]) for a, b in ((n - 3, n - 2), (n - 3, n - 1), (n - 2, n - 1))]
+    assert tail.tolist() == want
