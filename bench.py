@@ -381,7 +381,7 @@ def main():
             result["verify"] = {"rows_checked": len(probe), "rows_bad": bad}
             assert bad == 0, "multi-rank result differs from a single-engine run"
         if world == 1 and not args.no_cpu_baseline:
-            rows = min(n, 4000)
+            rows = min(n, 8000)
             host = codes[:rows].cpu().numpy()
             result["cpu_baseline"] = cpu_baseline(host, measure)
         if world == 1 and not args.no_extra:
