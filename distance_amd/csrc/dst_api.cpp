@@ -465,7 +465,7 @@ int dst_upload(dst_ctx *ctx, int slot, const uint8_t *codes, size_t n, size_t le
         return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
     if (n == 0)
         return fail(ctx, DST_ERR_ARG, "Empty FASTA file");  // src/fastaio.rs:97-99
-    if (!codes || row_stride < len)
+    if ((len && !codes) || row_stride < len)
         return fail(ctx, DST_ERR_ARG, "null codes or row_stride < len");
     if (n >= 0xFFFFFE00ull || len >= 0xFFFFFF00ull)
         return fail(ctx, DST_ERR_ARG, "n and len must fit 32 bits");
@@ -497,7 +497,7 @@ int dst_upload_device(dst_ctx *ctx, int slot, const void *d_codes, size_t n, siz
         return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
     if (n == 0)
         return fail(ctx, DST_ERR_ARG, "Empty FASTA file");
-    if (!d_codes || row_stride < len)
+    if ((len && !d_codes) || row_stride < len)
         return fail(ctx, DST_ERR_ARG, "null codes or row_stride < len");
     if (n >= 0xFFFFFE00ull || len >= 0xFFFFFF00ull)
         return fail(ctx, DST_ERR_ARG, "n and len must fit 32 bits");

@@ -155,3 +155,17 @@ def test_special_float_text(tmp_path):
     assert out[3] == "x\tn\tNaN"                    # 0/0
     out = cli(["-m", "tn93", str(f)]).splitlines()
     assert out[1] == "x\ty\t0.000000000000"         # src/measures.rs:188-190 normalises -0.0
+
+
+def test_fasta_corner_cases_through_the_cli(tmp_path):
+    """Header-only records (width 0), CRLF line ends, wrapped + lower-case sequence, descriptions."""
+    f = tmp_path / "empty_seqs.fasta"
+    f.write_text(">a\n>b some words\n>c\n")
+    out = cli(["-m", "raw", str(f)]).splitlines()
+    assert out == ["sequence1\tsequence2\tdistance", "a\tb\tNaN", "a\tc\tNaN", "b\tc\tNaN"]
+    assert cli(["-m", "n", str(f)]).splitlines()[1:] == ["a\tb\t0", "a\tc\t0", "b\tc\t0"]
+    g = tmp_path / "crlf.fasta"
+    g.write_bytes(b">x desc one\r\nACGT\r\nacgt\r\n>y\r\nACGTAC\r\nGA\r\n")
+    out = cli(["-m", "n_high", str(g)]).splitlines()
+    assert out[1] == "x\ty\t1"          # ACGTacgt vs ACGTACGA: one difference, case-insensitive
+    assert cli(["-m", "raw", str(g)]).splitlines()[1] == "x\ty\t0.125000000000"
