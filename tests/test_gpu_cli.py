@@ -169,3 +169,38 @@ def test_fasta_corner_cases_through_the_cli(tmp_path):
     out = cli(["-m", "n_high", str(g)]).splitlines()
     assert out[1] == "x\ty\t1"          # ACGTacgt vs ACGTACGA: one difference, case-insensitive
     assert cli(["-m", "raw", str(g)]).splitlines()[1] == "x\ty\t0.125000000000"
+
+
+def test_single_record_and_error_paths_with_gpu(tmp_path):
+    one = tmp_path / "one.fasta"
+    one.write_text(">only\nACGT\n")
+    assert cli(["-m", "raw", str(one)]) == "sequence1\tsequence2\tdistance\n"     # 0 pairs: header only
+    a = tmp_path / "a.fasta"
+    a.write_text(">a1\nACGT\n>a2\nACGA\n")
+    b = tmp_path / "b.fasta"
+    b.write_text(">b1\nACG\n")
+    r = subprocess.run([CLI, str(a), str(b)], capture_output=True)       # src/fastaio.rs:206-208
+    assert r.returncode == 1 and b"Different length sequences in alignment(s): 4 vs 3" in r.stderr
+    r = subprocess.run([CLI, "-i", str(a), "-s", str(b)], capture_output=True)   # src/fastaio.rs:246-248
+    assert r.returncode == 1 and b"Different length sequences in alignment(s): 3 vs 4" in r.stderr
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">s1\nACGT\n>s2\nAC*T\n")
+    r = subprocess.run([CLI, "-i", str(a), "-s", str(bad)], capture_output=True)
+    assert r.returncode == 1 and b"Invalid nucleotide character in record 's2': '*'" in r.stderr
+    empty = tmp_path / "empty.fasta"
+    empty.write_text("")
+    r = subprocess.run([CLI, "-i", str(a), "-s", str(empty)], capture_output=True)  # src/fastaio.rs:281-283
+    assert r.returncode == 1 and b"Empty FASTA file" in r.stderr
+    assert r.stdout == b"sequence1\tsequence2\tdistance\n"             # the header is already out, as in the reference
+
+
+def test_broken_pipe_exits_zero(tmp_path):
+    """handle_broken_pipe(): src/lib.rs:598-608 — a closed stdout is not an error."""
+    codes = random_alignment(400, 200, seed=13)
+    f = tmp_path / "a.fasta"
+    write_fasta(f, [f"s{i}" for i in range(len(codes))], to_text(codes))
+    p = subprocess.Popen([CLI, "-m", "n", str(f), "--slab-pairs", "2000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    first = p.stdout.readline()
+    p.stdout.close()
+    rc = p.wait(timeout=60)
+    assert first == b"sequence1\tsequence2\tdistance\n" and rc == 0, p.stderr.read()
