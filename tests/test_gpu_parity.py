@@ -466,3 +466,35 @@ def test_two_hundred_thousand_records(eng):
     tail = eng.run_square("n_high", n - 3, n)
     want = [oracle.pair_distance("n_high", codes[a], codes[b]) for a, b in ((n - 3, n - 2), (n - 3, n - 1), (n - 2, n - 1))]
     assert tail.tolist() == want
+
+
+def test_abi_argument_validation(eng):
+    """Every misuse comes back as a status code with a message; nothing aborts."""
+    import ctypes as C
+    lib, h = da.load(), eng._h
+    codes = random_alignment(10, 50, 99)
+    eng.upload(0, codes)
+    buf = np.zeros(45, np.float64)
+    p = buf.ctypes.data
+    ARG, STATE, CAP = 1, 4, 6
+    assert lib.dst_run_square_host(h, 2, 0, 11, 0, p, buf.nbytes) == ARG          # row_end > n
+    assert lib.dst_run_square_host(h, 2, 5, 4, 0, p, buf.nbytes) == ARG           # begin > end
+    assert lib.dst_run_square_host(h, 2, 0, 10, 0, p, 8 * 44) == CAP              # one pair short
+    assert lib.dst_run_square_host(h, 2, 0, 10, 7, p, buf.nbytes) == ARG          # unknown output kind
+    assert lib.dst_run_square_host(h, 9, 0, 10, 0, p, buf.nbytes) == ARG          # unknown measure
+    assert lib.dst_run_square_host(h, 2, 0, 10, 0, None, buf.nbytes) == ARG       # null output
+    assert lib.dst_run_square_host(None, 2, 0, 10, 0, p, buf.nbytes) == ARG       # null context
+    assert lib.dst_run_rect_host(h, 2, 0, 2, 0, 10, 0, p, buf.nbytes) == ARG      # slot out of range
+    assert lib.dst_upload(h, 2, codes.ctypes.data, 10, 50, 50, None) == ARG
+    assert lib.dst_upload(h, 0, codes.ctypes.data, 10, 50, 49, None) == ARG       # stride < len
+    assert lib.dst_upload(h, 0, None, 10, 50, 50, None) == ARG
+    assert b"Empty FASTA file" in lib.dst_last_error(h) or lib.dst_upload(h, 0, codes.ctypes.data, 0, 50, 50, None) == ARG
+    assert lib.dst_run_square_host(h, 2, 0, 0, 0, None, 0) == 0                   # empty range: nothing to do
+    n_, l_ = C.c_size_t(), C.c_size_t()
+    assert lib.dst_set_info(h, 0, C.byref(n_), C.byref(l_)) == 0 and (n_.value, l_.value) == (10, 50)
+    assert lib.dst_set_variant(h, -1) == ARG and lib.dst_set_ksplit(h, -3) == ARG
+    assert lib.dst_set_variant(h, 99) == 0                                        # unknown variant -> default tile
+    assert_close(eng.run_square("raw"), oracle.all_pairs_square("raw", codes))
+    eng.set_variant(0)
+    assert lib.dst_destroy(None) == 0
+    assert lib.dst_status_string(3) == b"invalid nucleotide code"
