@@ -374,9 +374,16 @@ void format_slab(const Job &job, Slab &slab)
             cut[k] = r;
         }
     }
+    // hot loop of the host side: one TSV line per pair, written with raw pointer bumps into a
+    // buffer that is grown geometrically (std::string::append per field costs ~4x more)
+    const bool is_int = job.measure == DST_N || job.measure == DST_N_HIGH;
     auto work = [&](size_t k) {
         std::string &out = parts[k];
-        char num[cli::kFixed12Max];
+        size_t pos = 0;
+        auto reserve = [&](size_t need) {
+            if (out.size() < pos + need)
+                out.resize(std::max(out.size() * 2, pos + need + (size_t)(1 << 16)));
+        };
         for (uint64_t i = cut[k]; i < cut[k + 1]; ++i) {
             const uint64_t j0 = job.square ? i + 1 : 0;
             uint64_t p = job.square ? dst_square_row_start(ncols, i) - dst_square_row_start(ncols, slab.rb)
@@ -394,16 +401,20 @@ void format_slab(const Job &job, Slab &slab)
                     dst_finalize(job.measure, &slab.tallies[p * w], rc, cc, &f, &iv);
                 const std::string &id1 = job.swap_ids ? job.cols->ids[j] : row_id;
                 const std::string &id2 = job.swap_ids ? row_id : job.cols->ids[j];
-                out.append(id1);
-                out.push_back('\t');
-                out.append(id2);
-                out.push_back('\t');
-                const int n = (job.measure == DST_N || job.measure == DST_N_HIGH) ? cli::fmt_i64(iv, num)
-                                                                                  : cli::fmt_fixed12(f, num);
-                out.append(num, (size_t)n);
-                out.push_back('\n');
+                reserve(id1.size() + id2.size() + 3 + cli::kFixed12Max);
+                char *o = &out[pos];
+                std::memcpy(o, id1.data(), id1.size());
+                o += id1.size();
+                *o++ = '\t';
+                std::memcpy(o, id2.data(), id2.size());
+                o += id2.size();
+                *o++ = '\t';
+                o += is_int ? cli::fmt_i64(iv, o) : cli::fmt_fixed12(f, o);
+                *o++ = '\n';
+                pos = (size_t)(o - out.data());
             }
         }
+        out.resize(pos);
     };
     if (T == 1) {
         work(0);
