@@ -23,6 +23,8 @@ struct FastaRecord {
 class FastaReader {
 public:
     explicit FastaReader(FILE *fh) : fh_(fh) {}
+    // parse an in-memory block (whole records, as cut by BlockReader)
+    FastaReader(const char *data, size_t len) : fh_(nullptr), mem_(data), mem_len_(len) {}
     // 1 = a record was read, 0 = end of input, -1 = format error (message in error())
     int next(FastaRecord &rec)
     {
@@ -70,6 +72,16 @@ private:
     bool read_line()  // false at EOF with nothing read
     {
         line_.clear();
+        if (mem_) {  // in-memory block: one memchr per line
+            if (mem_pos_ >= mem_len_)
+                return false;
+            const char *start = mem_ + mem_pos_;
+            const char *nl = (const char *)std::memchr(start, '\n', mem_len_ - mem_pos_);
+            const size_t n = nl ? (size_t)(nl - start) + 1 : mem_len_ - mem_pos_;
+            line_.assign(start, n);
+            mem_pos_ += n;
+            return true;
+        }
         for (;;) {
             if (pos_ == len_) {
                 len_ = std::fread(buf_, 1, sizeof buf_, fh_);
@@ -89,9 +101,66 @@ private:
         }
     }
     FILE *fh_;
+    const char *mem_ = nullptr;
+    size_t mem_len_ = 0, mem_pos_ = 0;
     std::string line_, err_;
     char buf_[1 << 16];
     size_t pos_ = 0, len_ = 0;
+};
+
+// Cuts a stream into blocks of whole records so that blocks can be parsed in parallel: a block ends
+// just before a line that starts with '>' (every such line starts a record for bio's reader).
+class BlockReader {
+public:
+    BlockReader(FILE *fh, size_t target_bytes) : fh_(fh), target_(target_bytes ? target_bytes : 1) {}
+    // false at end of input; otherwise `out` holds >= 1 whole record (the rest of the input at EOF)
+    bool next(std::string &out)
+    {
+        out.clear();
+        for (;;) {
+            if (!eof_ && carry_.size() < target_) {
+                const size_t old = carry_.size();
+                carry_.resize(old + target_);
+                const size_t got = std::fread(&carry_[old], 1, target_, fh_);
+                carry_.resize(old + got);
+                if (got == 0)
+                    eof_ = true;
+            }
+            if (carry_.empty())
+                return false;
+            if (eof_) {
+                out.swap(carry_);
+                carry_.clear();
+                return true;
+            }
+            // last "\n>" in the buffer: everything before the '>' is whole records
+            size_t cut = std::string::npos;
+            for (size_t p = carry_.size(); p-- > 1;) {
+                if (carry_[p] == '>' && carry_[p - 1] == '\n') {
+                    cut = p;
+                    break;
+                }
+            }
+            if (cut != std::string::npos && cut > 0) {
+                out.assign(carry_, 0, cut);
+                carry_.erase(0, cut);
+                return true;
+            }
+            // one record longer than the target: keep reading
+            const size_t old = carry_.size();
+            carry_.resize(old + target_);
+            const size_t got = std::fread(&carry_[old], 1, target_, fh_);
+            carry_.resize(old + got);
+            if (got == 0)
+                eof_ = true;
+        }
+    }
+
+private:
+    FILE *fh_;
+    size_t target_;
+    std::string carry_;
+    bool eof_ = false;
 };
 
 }  // namespace cli

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <csignal>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -39,10 +41,19 @@ const char *kVersion = "0.3.1";  // Cargo.toml:3 of the reference this CLI mirro
 
 // ---------------------------------------------------------------- errors ----------------------
 // main() of the reference returns Result<(), DistanceError>: Rust prints `Error: {:?}` and exits 1.
+// Fatal errors can surface on a reader / worker thread while GPU threads are still running: flush
+// what was written (the reference's BufWriter content is flushed on its way out too) and leave
+// without running static destructors under those threads.
+[[noreturn]] void leave(int code)
+{
+    std::fflush(nullptr);
+    _exit(code);
+}
+
 [[noreturn]] void die_message(const std::string &m)
 {
     std::fprintf(stderr, "Error: Message(\"%s\")\n", m.c_str());
-    std::exit(1);
+    leave(1);
 }
 
 [[noreturn]] void die_io(const std::string &what, int err)
@@ -50,7 +61,7 @@ const char *kVersion = "0.3.1";  // Cargo.toml:3 of the reference this CLI mirro
     std::fprintf(stderr, "Error: IOError(Os { code: %d, kind: %s, message: \"%s\" }) [%s]\n", err,
                  err == ENOENT ? "NotFound" : err == EACCES ? "PermissionDenied" : "Other", std::strerror(err),
                  what.c_str());
-    std::exit(1);
+    leave(1);
 }
 
 [[noreturn]] void die_usage(const std::string &m)
@@ -237,32 +248,6 @@ std::string err_lengths(size_t w1, size_t w2)  // src/fastaio.rs:93-95
     return "Different length sequences in alignment(s): " + std::to_string(w1) + " vs " + std::to_string(w2);
 }
 
-// encode() / encode_count_bases(): src/fastaio.rs:101-145
-void encode_into(const cli::FastaRecord &rec, const uint8_t *table, Alignment &al, bool count_raw_upper)
-{
-    const size_t at = al.codes.size();
-    al.codes.resize(at + rec.seq.size());
-    uint32_t counting[256];
-    if (count_raw_upper)
-        std::memset(counting, 0, sizeof counting);
-    for (size_t i = 0; i < rec.seq.size(); ++i) {
-        const unsigned char c = (unsigned char)rec.seq[i];
-        if (table[c] == 0)
-            die_message(err_invalid_nuc(rec.id, c));
-        al.codes[at + i] = table[c];
-        if (count_raw_upper)
-            counting[c] += 1;
-    }
-    if (count_raw_upper) {
-        al.counts.push_back(counting['A']);
-        al.counts.push_back(counting['T']);
-        al.counts.push_back(counting['G']);
-        al.counts.push_back(counting['C']);
-    }
-    al.ids.push_back(rec.id);
-    al.n += 1;
-}
-
 FILE *open_input(const std::string &path)
 {
     FILE *fh = std::fopen(path.c_str(), "rb");
@@ -271,27 +256,132 @@ FILE *open_input(const std::string &path)
     return fh;
 }
 
-// load_fasta(): src/fastaio.rs:174-199
-Alignment load_fasta(FILE *fh, const uint8_t *table)
+// One block of whole records -> encoded records.  Errors are returned, not raised, so that the
+// consumer reports the FIRST one in file order, like the reference's sequential reader.
+struct ParsedBlock {
+    std::unique_ptr<Alignment> al;
+    std::string error;  // empty: ok
+    bool stop = false;  // an empty record ended bio's Records iterator: nothing after it is read
+};
+
+ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool count_raw_upper, bool fixed_width,
+                        size_t width)
 {
-    Alignment al;
-    cli::FastaReader reader(fh);
+    ParsedBlock out;
+    out.al = std::make_unique<Alignment>();
+    Alignment &al = *out.al;
+    al.width = width;
+    cli::FastaReader reader(block.data(), block.size());
     cli::FastaRecord rec;
-    bool first = true;
+    bool first = !fixed_width;
     for (;;) {
         const int rc = reader.next(rec);
-        if (rc < 0)
-            die_message(reader.error());
-        if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty()))
-            break;  // bio's Records iterator stops at an empty record
-        encode_into(rec, table, al, false);
+        if (rc < 0) {
+            out.error = reader.error();
+            return out;
+        }
+        if (rc == 0)
+            break;
+        if (rec.id.empty() && !rec.has_desc && rec.seq.empty()) {
+            out.stop = true;  // bio's Records iterator stops at an empty record
+            break;
+        }
         if (first) {
             al.width = rec.seq.size();
             first = false;
         } else if (rec.seq.size() != al.width) {
-            die_message(err_lengths(rec.seq.size(), al.width));
+            out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 188-190, 246-248
+            return out;
+        }
+        // encode() / encode_count_bases(): src/fastaio.rs:101-145
+        const size_t at = al.codes.size();
+        al.codes.resize(at + rec.seq.size());
+        uint32_t counting[256];
+        if (count_raw_upper)
+            std::memset(counting, 0, sizeof counting);
+        for (size_t i = 0; i < rec.seq.size(); ++i) {
+            const unsigned char c = (unsigned char)rec.seq[i];
+            if (table[c] == 0) {
+                out.error = err_invalid_nuc(rec.id, c);
+                return out;
+            }
+            al.codes[at + i] = table[c];
+            if (count_raw_upper)
+                counting[c] += 1;
+        }
+        if (count_raw_upper) {
+            al.counts.push_back(counting['A']);
+            al.counts.push_back(counting['T']);
+            al.counts.push_back(counting['G']);
+            al.counts.push_back(counting['C']);
+        }
+        al.ids.push_back(rec.id);
+        al.n += 1;
+    }
+    return out;
+}
+
+// Reads `fh` block by block and parses up to `lookahead` blocks concurrently; `consume` gets the
+// parsed blocks strictly in file order (and is where errors surface).
+template <class Consume>
+void parse_stream(FILE *fh, size_t block_bytes, size_t lookahead, const uint8_t *table, bool count_raw_upper,
+                  bool fixed_width, size_t width, Consume consume)
+{
+    cli::BlockReader blocks(fh, block_bytes);
+    std::deque<std::future<ParsedBlock>> inflight;
+    std::string block;
+    bool more = true, width_known = fixed_width;
+    size_t w = width;
+    while (more || !inflight.empty()) {
+        // the first block runs alone when the width is not known yet (it fixes it for the others)
+        while (more && inflight.size() < (width_known ? std::max<size_t>(lookahead, 1) : 1)) {
+            if (!blocks.next(block)) {
+                more = false;
+                break;
+            }
+            inflight.push_back(std::async(std::launch::async,
+                                          [b = std::move(block), table, count_raw_upper, width_known, w]() {
+                                              return parse_block(b, table, count_raw_upper, width_known, w);
+                                          }));
+            block.clear();
+        }
+        if (inflight.empty())
+            break;
+        ParsedBlock pb = inflight.front().get();
+        inflight.pop_front();
+        if (!pb.error.empty())
+            die_message(pb.error);
+        if (!width_known && pb.al->n) {
+            width_known = true;
+            w = pb.al->width;
+        }
+        const bool stop = pb.stop;
+        consume(std::move(pb.al));
+        if (stop) {
+            for (auto &f : inflight)
+                f.wait();
+            return;
         }
     }
+}
+
+// load_fasta(): src/fastaio.rs:174-199 (blocks parsed in parallel, assembled in file order)
+Alignment load_fasta(FILE *fh, const uint8_t *table, size_t threads)
+{
+    Alignment al;
+    bool first = true;
+    parse_stream(fh, (size_t)32 << 20, threads, table, false, false, 0, [&](std::unique_ptr<Alignment> part) {
+        if (part->n == 0)
+            return;
+        if (first) {
+            al.width = part->width;
+            first = false;
+        }
+        al.codes.insert(al.codes.end(), part->codes.begin(), part->codes.end());
+        for (auto &id : part->ids)
+            al.ids.push_back(std::move(id));
+        al.n += part->n;
+    });
     if (al.n == 0)
         die_message("Empty FASTA file");  // src/fastaio.rs:97-99
     return al;
@@ -306,7 +396,7 @@ struct Writer {
             return;
         if (std::fwrite(p, 1, n, fh) != n) {
             if (errno == EPIPE)
-                std::exit(0);  // handle_broken_pipe(): src/lib.rs:598-608
+                _exit(0);  // handle_broken_pipe(): src/lib.rs:598-608
             die_io("write", errno);
         }
     }
@@ -314,7 +404,7 @@ struct Writer {
     {
         if (std::fflush(fh) != 0) {
             if (errno == EPIPE)
-                std::exit(0);
+                _exit(0);
             die_io("flush", errno);
         }
     }
@@ -326,16 +416,33 @@ struct Ctx {
     {
         if (rc != DST_OK) {
             std::fprintf(stderr, "Error: Gpu(\"%s: %s\")\n", what, dst_last_error(h));
-            std::exit(1);
+            leave(1);
         }
     }
 };
 
 // One slab of results: rows [rb, re) of the row set against the column set (square: j > i).
+// un-initialised growable char buffer (std::string::resize would zero-fill every byte first)
+struct TextBuf {
+    std::unique_ptr<char[]> p;
+    size_t len = 0, cap = 0;
+    void ensure(size_t need)
+    {
+        if (len + need <= cap)
+            return;
+        const size_t ncap = std::max(cap + cap / 2, len + need + ((size_t)1 << 16));
+        std::unique_ptr<char[]> q(new char[ncap]);
+        if (len)
+            std::memcpy(q.get(), p.get(), len);
+        p = std::move(q);
+        cap = ncap;
+    }
+};
+
 struct Slab {
     uint64_t rb = 0, re = 0;
-    std::vector<uint32_t> tallies;
-    std::string text;
+    std::unique_ptr<uint32_t[]> tallies;  // un-initialised: the GPU run overwrites all of it
+    std::vector<TextBuf> text;            // formatted parts, in canonical order
 };
 
 struct Job {
@@ -355,7 +462,8 @@ void format_slab(const Job &job, Slab &slab)
     const uint64_t ncols = job.cols->n;
     const uint64_t rows = slab.re - slab.rb;
     const size_t T = std::max<size_t>(1, std::min<size_t>(job.fmt_threads, rows));
-    std::vector<std::string> parts(T);
+    slab.text.clear();
+    slab.text.resize(T);
     // split rows so that each part has about the same number of pairs
     std::vector<uint64_t> cut(T + 1, slab.re);
     cut[0] = slab.rb;
@@ -377,13 +485,18 @@ void format_slab(const Job &job, Slab &slab)
     // hot loop of the host side: one TSV line per pair, written with raw pointer bumps into a
     // buffer that is grown geometrically (std::string::append per field costs ~4x more)
     const bool is_int = job.measure == DST_N || job.measure == DST_N_HIGH;
+    auto pairs_between = [&](uint64_t r0, uint64_t r1) -> uint64_t {
+        if (!job.square)
+            return (r1 - r0) * ncols;
+        return dst_square_row_start(ncols, r1) - dst_square_row_start(ncols, r0);
+    };
+    size_t id_max = 0;
+    for (const auto &id : job.cols->ids)
+        id_max = std::max(id_max, id.size());
     auto work = [&](size_t k) {
-        std::string &out = parts[k];
-        size_t pos = 0;
-        auto reserve = [&](size_t need) {
-            if (out.size() < pos + need)
-                out.resize(std::max(out.size() * 2, pos + need + (size_t)(1 << 16)));
-        };
+        TextBuf &out = slab.text[k];
+        // first guess: 16 characters of number per line; grows (rarely) if a line needs more
+        out.ensure((size_t)pairs_between(cut[k], cut[k + 1]) * (id_max + 20) + 64);
         for (uint64_t i = cut[k]; i < cut[k + 1]; ++i) {
             const uint64_t j0 = job.square ? i + 1 : 0;
             uint64_t p = job.square ? dst_square_row_start(ncols, i) - dst_square_row_start(ncols, slab.rb)
@@ -401,8 +514,8 @@ void format_slab(const Job &job, Slab &slab)
                     dst_finalize(job.measure, &slab.tallies[p * w], rc, cc, &f, &iv);
                 const std::string &id1 = job.swap_ids ? job.cols->ids[j] : row_id;
                 const std::string &id2 = job.swap_ids ? row_id : job.cols->ids[j];
-                reserve(id1.size() + id2.size() + 3 + cli::kFixed12Max);
-                char *o = &out[pos];
+                out.ensure(id1.size() + id2.size() + 3 + cli::kFixed12Max);
+                char *o = out.p.get() + out.len;
                 std::memcpy(o, id1.data(), id1.size());
                 o += id1.size();
                 *o++ = '\t';
@@ -411,10 +524,9 @@ void format_slab(const Job &job, Slab &slab)
                 *o++ = '\t';
                 o += is_int ? cli::fmt_i64(iv, o) : cli::fmt_fixed12(f, o);
                 *o++ = '\n';
-                pos = (size_t)(o - out.data());
+                out.len = (size_t)(o - out.p.get());
             }
         }
-        out.resize(pos);
     };
     if (T == 1) {
         work(0);
@@ -426,13 +538,6 @@ void format_slab(const Job &job, Slab &slab)
         for (auto &t : th)
             t.join();
     }
-    size_t total = 0;
-    for (auto &s : parts)
-        total += s.size();
-    slab.text.clear();
-    slab.text.reserve(total);
-    for (auto &s : parts)
-        slab.text.append(s);
 }
 
 // rows [0, n_rows) cut into slabs of <= max_pairs pairs (at least one row each)
@@ -483,15 +588,15 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
             s->re = slabs[k].second;
             const uint64_t pairs = job.square ? dst_square_row_start(job.cols->n, s->re) - dst_square_row_start(job.cols->n, s->rb)
                                               : (s->re - s->rb) * job.cols->n;
-            s->tallies.resize((size_t)pairs * w);
+            const size_t n_tallies = (size_t)pairs * w;
+            s->tallies.reset(new uint32_t[std::max<size_t>(n_tallies, 1)]);
             const int rc = job.square ? dst_run_square_host(gpus[g].h, job.measure, s->rb, s->re, DST_OUT_TALLY,
-                                                            s->tallies.data(), s->tallies.size() * 4)
+                                                            s->tallies.get(), n_tallies * 4)
                                       : dst_run_rect_host(gpus[g].h, job.measure, row_slot, col_slot, s->rb, s->re,
-                                                          DST_OUT_TALLY, s->tallies.data(), s->tallies.size() * 4);
+                                                          DST_OUT_TALLY, s->tallies.get(), n_tallies * 4);
             gpus[g].check(rc, "run");
             format_slab(job, *s);
-            s->tallies.clear();
-            s->tallies.shrink_to_fit();
+            s->tallies.reset();
             {
                 std::lock_guard<std::mutex> lk(mu);
                 ready[k] = std::move(s);
@@ -510,7 +615,8 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
             cv.wait(lk, [&] { return ready[next_to_write] != nullptr; });
             s = std::move(ready[next_to_write]);
         }
-        wr.write(s->text.data(), s->text.size());
+        for (const TextBuf &part : s->text)
+            wr.write(part.p.get(), part.len);
         {
             std::lock_guard<std::mutex> lk(mu);
             ++next_to_write;
@@ -567,8 +673,25 @@ int host_selftest(const Args &a)
 
 }  // namespace
 
+// DISTANCE_TIMING=1: phase wall times on stderr
+struct PhaseTimer {
+    bool on = std::getenv("DISTANCE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char *what)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[timing] %-28s %8.1f ms (total %8.1f ms)\n", what,
+                     std::chrono::duration<double, std::milli>(now - last).count(),
+                     std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 int main(int argc, char **argv)
 {
+    PhaseTimer timer;
     std::signal(SIGPIPE, SIG_IGN);  // EPIPE is handled at the write (exit 0), like the reference
     Args a = parse_args(argc, argv);
     if (!a.selftest.empty())
@@ -595,12 +718,16 @@ int main(int argc, char **argv)
     }
     uint8_t table[256];
     encoding_array(table);
+    const size_t threads = a.has_threads ? std::max<size_t>(a.threads, 1)  // src/lib.rs:253-263
+                                         : std::max<unsigned>(1, std::thread::hardware_concurrency());
+    const size_t parse_threads = std::min<size_t>(threads, 16);
     std::vector<Alignment> loaded;
     for (size_t k = 0; k < files.size(); ++k) {  // load_fastas(): src/fastaio.rs:202-212
-        loaded.push_back(load_fasta(files[k], table));
+        loaded.push_back(load_fasta(files[k], table, parse_threads));
         if (k == 1 && loaded[0].width != loaded[1].width)
             die_message(err_lengths(loaded[0].width, loaded[1].width));
     }
+    timer.mark("parse + encode loaded files");
     Writer wr;
     if (a.has_output) {
         wr.fh = std::fopen(a.output.c_str(), "wb");
@@ -609,8 +736,6 @@ int main(int argc, char **argv)
     }
     static char outbuf[1 << 20];
     std::setvbuf(wr.fh, outbuf, _IOFBF, sizeof outbuf);
-    size_t threads = a.has_threads ? std::max<size_t>(a.threads, 1)  // src/lib.rs:253-263
-                                   : std::max<unsigned>(1, std::thread::hardware_concurrency());
 
     const int measure = dst_measure_from_name(a.measure.c_str());
     // ---- GPUs ----------------------------------------------------------------------------------
@@ -632,6 +757,7 @@ int main(int argc, char **argv)
             return 1;
         }
     }
+    timer.mark("HIP init + contexts");
     for (int g = 0; g < G; ++g)
         for (size_t k = 0; k < loaded.size(); ++k)
             gpus[g].check(dst_upload(gpus[g].h, (int)k, loaded[k].codes.data(), loaded[k].n, loaded[k].width,
@@ -645,6 +771,7 @@ int main(int argc, char **argv)
             gpus[0].check(dst_get_base_counts(gpus[0].h, (int)k, counts[k].data()), "base counts");
         }
 
+    timer.mark("upload + pack + counts");
     static const char header[] = "sequence1\tsequence2\tdistance\n";  // src/lib.rs:613
     wr.write(header, sizeof header - 1);
 
@@ -675,33 +802,19 @@ int main(int argc, char **argv)
         std::deque<std::unique_ptr<Alignment>> queue;
         bool reader_done = false;
         size_t record_counter = 0;
+        // bytes of FASTA per parsed block ~ records per batch
+        const size_t block_bytes = std::max<size_t>(batch_records * (ref.width + 64), (size_t)1 << 20);
         std::thread reader_thread([&] {
-            cli::FastaReader reader(stream_fh);
-            cli::FastaRecord rec;
-            bool eof = false;
-            while (!eof) {
-                auto batch = std::make_unique<Alignment>();
-                batch->width = ref.width;
-                while (batch->n < batch_records) {
-                    const int rc = reader.next(rec);
-                    if (rc < 0)
-                        die_message(reader.error());
-                    if (rc == 0 || (rec.id.empty() && !rec.has_desc && rec.seq.empty())) {
-                        eof = true;
-                        break;
-                    }
-                    record_counter += 1;
-                    if (rec.seq.size() != ref.width)
-                        die_message(err_lengths(rec.seq.size(), ref.width));  // src/fastaio.rs:246-248
-                    encode_into(rec, table, *batch, measure == DST_TN93);    // tn93: raw upper-case counts (:136-142)
-                }
-                if (batch->n == 0)
-                    break;
-                std::unique_lock<std::mutex> lk(qmu);
-                qcv.wait(lk, [&] { return queue.size() < 2; });
-                queue.push_back(std::move(batch));
-                qcv.notify_all();
-            }
+            parse_stream(stream_fh, block_bytes, parse_threads, table, measure == DST_TN93, true, ref.width,
+                         [&](std::unique_ptr<Alignment> batch) {
+                             if (batch->n == 0)
+                                 return;
+                             record_counter += batch->n;
+                             std::unique_lock<std::mutex> lk(qmu);
+                             qcv.wait(lk, [&] { return queue.size() < 2; });
+                             queue.push_back(std::move(batch));
+                             qcv.notify_all();
+                         });
             std::lock_guard<std::mutex> lk(qmu);
             reader_done = true;
             qcv.notify_all();
@@ -734,8 +847,11 @@ int main(int argc, char **argv)
         if (record_counter == 0)
             die_message("Empty FASTA file");  // src/fastaio.rs:281-283
     }
+    timer.mark("compute + format + write");
     wr.flush();
+    timer.mark("flush");
     for (auto &g : gpus)
         dst_destroy(g.h);
+    timer.mark("destroy contexts");
     return 0;
 }
