@@ -647,6 +647,20 @@ int host_selftest(const Args &a)
         }
         return 0;
     }
+    if (a.selftest == "fasta-blocks") {  // the same through BlockReader + parallel parse, tiny blocks
+        uint8_t table[256];
+        encoding_array(table);
+        std::memset(table, 1, 256);  // accept every byte: this mode checks tokenisation only
+        size_t total = 0;
+        parse_stream(stdin, a.slab_pairs < 4096 ? a.slab_pairs : 7, 4, table, false, false, 0,
+                     [&](std::unique_ptr<Alignment> part) {
+                         for (size_t r = 0; r < part->n; ++r)
+                             std::printf("%s\t%zu\n", part->ids[r].c_str(), part->width);
+                         total += part->n;
+                     });
+        std::printf("records\t%zu\n", total);
+        return 0;
+    }
     if (a.selftest == "format") {  // hex floats on stdin -> {:.12}
         char line[256], out[512];
         while (std::fgets(line, sizeof line, stdin)) {

@@ -101,3 +101,23 @@ def test_set_up_errors_before_any_gpu_work(tmp_path):
     empty.write_text("")
     r = run([str(empty)])                 # src/fastaio.rs:97-99
     assert r.returncode == 1 and b"Empty FASTA file" in r.stderr
+
+
+def test_block_parallel_parser_matches_the_sequential_reader():
+    """BlockReader + parse_stream (blocks of 5..64 bytes) see the same records as FastaReader."""
+    texts = [
+        b">s1 d\nACGT\nAC\n>s2\r\nAAAAAA\r\n>s3\nCC\nGG\nTT\n",
+        b">only\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n",
+        b">a\nAC>GT\n>b\nACGGT\n",                    # '>' inside a line is sequence text, not a header
+        b">a\nAAAA\n\n\n>b\nCCCC",                     # blank lines, no final newline
+        b"",
+    ]
+    for text in texts:
+        seq = [l.split("\t") for l in run(["--host-selftest", "fasta"], text).stdout.decode().splitlines()]
+        want = [f"{r[0]}\t{len(r[2])}" for r in seq] + [f"records\t{len(seq)}"]
+        for blk in ("5", "9", "64"):
+            got = run(["--host-selftest", "fasta-blocks", "--slab-pairs", blk], text).stdout.decode().splitlines()
+            assert got == want, (text, blk)
+    # ragged widths are an error in file order, whichever block they fall in (src/fastaio.rs:188-190)
+    r = run(["--host-selftest", "fasta-blocks", "--slab-pairs", "6"], b">a\nACGT\n>b\nACG\n>c\nACGT\n")
+    assert r.returncode == 1 and b"Different length sequences in alignment(s): 3 vs 4" in r.stderr
