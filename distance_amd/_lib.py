@@ -63,6 +63,8 @@ _SIGS = {
     "dst_run_rect_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
                                     C.c_size_t]),
     "dst_run_slabs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
+    "dst_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "dst_host_free": (C.c_int, [_vp]),
     "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),
     "dst_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "dst_plan_tiles": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp,

@@ -111,7 +111,7 @@ struct Args {
     size_t threads = 0, batchsize = 1;
     int gpus = 1;
     std::vector<int> devices;  // explicit device ordinals (--devices 0,1,..); empty: 0..gpus-1
-    size_t slab_pairs = (size_t)1 << 24;
+    size_t slab_pairs = (size_t)1 << 22;  // result slab: 4 Mi pairs pipelines GPU, formatters and writer well
     std::string selftest;
 };
 
@@ -439,9 +439,47 @@ struct TextBuf {
     }
 };
 
+// page-locked result buffers, recycled between slabs (pinning pages costs more than the copy)
+class PinnedPool {
+public:
+    ~PinnedPool()
+    {
+        for (auto &b : free_)
+            dst_host_free(b.first);
+    }
+    uint32_t *acquire(size_t bytes, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t k = 0; k < free_.size(); ++k)
+                if (free_[k].second >= bytes) {
+                    auto b = free_[k];
+                    free_.erase(free_.begin() + (long)k);
+                    *cap = b.second;
+                    return static_cast<uint32_t *>(b.first);
+                }
+        }
+        void *p = nullptr;
+        if (dst_host_alloc(bytes, &p) != DST_OK)
+            return nullptr;
+        *cap = bytes;
+        return static_cast<uint32_t *>(p);
+    }
+    void release(uint32_t *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        free_.emplace_back(p, cap);
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::pair<void *, size_t>> free_;
+};
+
 struct Slab {
     uint64_t rb = 0, re = 0;
-    std::unique_ptr<uint32_t[]> tallies;  // un-initialised: the GPU run overwrites all of it
+    uint32_t *tallies = nullptr;  // page-locked (PinnedPool): the copy back runs at link speed
+    size_t tallies_cap = 0;
     std::vector<TextBuf> text;            // formatted parts, in canonical order
 };
 
@@ -562,23 +600,32 @@ std::vector<std::pair<uint64_t, uint64_t>> make_slabs(bool square, uint64_t n_ro
 }
 
 // Compute every slab on the GPUs (slab k on GPU k mod G), format on the host pool, write in order.
+// Three stages, like the reference's generator -> workers -> gather_write (src/lib.rs:377-458):
+//   GPU threads (one per context): slab k's tallies into page-locked memory, slab k on context k mod G;
+//   formatter threads: tallies -> exact TSV text (each fans out over its share of the -t pool);
+//   the calling thread: writes slabs strictly in canonical order (gather_write's idx re-ordering).
 void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slot, uint64_t max_pairs, Writer &wr)
 {
     const auto slabs = make_slabs(job.square, job.rows->n, job.cols->n, max_pairs);
     const int w = dst_tally_width(job.measure);
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::unique_ptr<Slab>> done;  // finished slabs, any order
     size_t next_to_write = 0;
     std::atomic<size_t> next_slab{0};
-    const size_t window = gpus.size() * 2 + 1;  // bound on slabs in flight (memory)
+    const size_t n_formatters = 2;
+    const size_t window = gpus.size() * 2 + n_formatters + 1;  // bound on slabs in flight (memory)
+    PinnedPool pool;
+    std::deque<std::pair<size_t, std::unique_ptr<Slab>>> computed;  // GPU done, waiting for a formatter
+    size_t gpu_threads_left = gpus.size();
     std::vector<std::unique_ptr<Slab>> ready(slabs.size());
+    Job fjob = job;
+    fjob.fmt_threads = std::max<size_t>(1, job.fmt_threads / n_formatters);
 
     auto gpu_worker = [&](size_t g) {
         for (;;) {
             const size_t k = next_slab.fetch_add(1);
             if (k >= slabs.size())
-                return;
+                break;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return k < next_to_write + window; });
@@ -589,17 +636,41 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
             const uint64_t pairs = job.square ? dst_square_row_start(job.cols->n, s->re) - dst_square_row_start(job.cols->n, s->rb)
                                               : (s->re - s->rb) * job.cols->n;
             const size_t n_tallies = (size_t)pairs * w;
-            s->tallies.reset(new uint32_t[std::max<size_t>(n_tallies, 1)]);
+            s->tallies = pool.acquire(std::max<size_t>(n_tallies, 1) * 4, &s->tallies_cap);
+            if (!s->tallies)
+                gpus[g].check(DST_ERR_NOMEM, "pinned host buffer");
             const int rc = job.square ? dst_run_square_host(gpus[g].h, job.measure, s->rb, s->re, DST_OUT_TALLY,
-                                                            s->tallies.get(), n_tallies * 4)
+                                                            s->tallies, n_tallies * 4)
                                       : dst_run_rect_host(gpus[g].h, job.measure, row_slot, col_slot, s->rb, s->re,
-                                                          DST_OUT_TALLY, s->tallies.get(), n_tallies * 4);
+                                                          DST_OUT_TALLY, s->tallies, n_tallies * 4);
             gpus[g].check(rc, "run");
-            format_slab(job, *s);
-            s->tallies.reset();
             {
                 std::lock_guard<std::mutex> lk(mu);
-                ready[k] = std::move(s);
+                computed.emplace_back(k, std::move(s));
+            }
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        --gpu_threads_left;
+        cv.notify_all();
+    };
+    auto formatter = [&]() {
+        for (;;) {
+            std::pair<size_t, std::unique_ptr<Slab>> item;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !computed.empty() || gpu_threads_left == 0; });
+                if (computed.empty())
+                    return;
+                item = std::move(computed.front());
+                computed.pop_front();
+            }
+            format_slab(fjob, *item.second);
+            pool.release(item.second->tallies, item.second->tallies_cap);
+            item.second->tallies = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[item.first] = std::move(item.second);
             }
             cv.notify_all();
         }
@@ -607,6 +678,8 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
     std::vector<std::thread> workers;
     for (size_t g = 0; g < gpus.size(); ++g)
         workers.emplace_back(gpu_worker, g);
+    for (size_t f = 0; f < n_formatters; ++f)
+        workers.emplace_back(formatter);
     // ordered writer (the reference's gather_write re-orders by batch idx: src/lib.rs:616-637)
     while (next_to_write < slabs.size()) {
         std::unique_ptr<Slab> s;

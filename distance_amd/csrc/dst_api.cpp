@@ -595,6 +595,22 @@ int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int
     return DST_OK;
 }
 
+int dst_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr)
+        return DST_ERR_ARG;
+    *ptr = nullptr;
+    const hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    return e == hipSuccess ? DST_OK : (e == hipErrorOutOfMemory ? DST_ERR_NOMEM : DST_ERR_HIP);
+}
+
+int dst_host_free(void *ptr)
+{
+    if (!ptr)
+        return DST_OK;
+    return hipHostFree(ptr) == hipSuccess ? DST_OK : DST_ERR_HIP;
+}
+
 int dst_run_slabs(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot, int out_kind,
                   uint64_t max_pairs, dst_slab_sink sink, void *user)
 {

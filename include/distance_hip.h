@@ -150,6 +150,10 @@ typedef int (*dst_slab_sink)(void *user, uint64_t first_pair, uint64_t n_pairs, 
                              uint64_t row_end, const void *data);
 int dst_run_slabs(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot, int out_kind,
                   uint64_t max_pairs, dst_slab_sink sink, void *user);
+/* Page-locked host memory for the *_host forms' output buffers (copy-back by DMA at link speed instead
+ * of through a pageable bounce buffer).  Free with dst_host_free. */
+int dst_host_alloc(size_t bytes, void **ptr);
+int dst_host_free(void *ptr);
 /* bytes a run writes */
 size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs);
 /* milliseconds of the pair kernel of the most recent run and of the pack kernel of the most recent
