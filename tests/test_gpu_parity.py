@@ -498,3 +498,30 @@ def test_abi_argument_validation(eng):
     eng.set_variant(0)
     assert lib.dst_destroy(None) == 0
     assert lib.dst_status_string(3) == b"invalid nucleotide code"
+
+
+def test_contexts_release_their_device_memory():
+    """Create / upload / run / destroy in a loop: free HBM returns to where it started."""
+    import torch
+    torch.cuda.init()
+    codes = random_alignment(600, 4000, 55)
+    other = random_alignment(64, 4000, 56)
+
+    def cycle():
+        e = da.Engine(0)
+        e.upload(0, codes)
+        e.upload(1, other)
+        e.run_square("tn93")
+        e.set_ksplit(8)
+        e.run_rect("raw")
+        e.run_slabs("n_high", lambda *a: None, 5000)
+        e.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < (64 << 20), (free0, free1)
