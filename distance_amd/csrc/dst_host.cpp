@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -55,6 +56,18 @@ std::vector<BlockDesc> build_blocks(bool square, uint64_t row_begin, uint64_t ro
         return out;
     const uint64_t BM = (uint64_t)ts.bm, BN = (uint64_t)ts.bn;
     const uint64_t n_panels = (n_cols + BN - 1) / BN;
+    // measurement knob (tools/kbench.py): DST_SCHEDULE=rowmajor deals tiles row tile by row tile
+    // with no regard for XCDs, to price the panel-per-XCD schedule below against it
+    const char *mode = std::getenv("DST_SCHEDULE");
+    if (mode && std::strcmp(mode, "rowmajor") == 0) {
+        for (uint64_t i0 = row_begin; i0 < row_end; i0 += BM)
+            for (uint64_t pj = 0; pj < n_panels; ++pj) {
+                const uint64_t jmax = std::min(n_cols, pj * BN + BN) - 1;
+                if (!square || i0 < jmax)
+                    out.push_back({(uint32_t)i0, (uint32_t)(pj * BN)});
+            }
+        return out;
+    }
 
     struct Panel {
         uint64_t j0, first_row, n_tiles;
