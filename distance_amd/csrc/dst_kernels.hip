@@ -362,6 +362,17 @@ __device__ __forceinline__ double finalize_pair(const uint32_t *o, uint4 qc, uin
 //            itself: the lane's tallies go through a lane-private LDS slot so that ONE copy of the
 //            (log-heavy) finalisation code runs in a rolled loop instead of BM*TN inlined copies;
 //            no tally round trip through HBM, no second kernel.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane from (wave-uniform base) + (per-lane byte offset < 2^32): buffer_load_dwordx4 ... offen
+__device__ __forceinline__ uint4 load_columns(const uint4 *uniform_base, uint32_t lane_byte)
+{
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(uniform_base), 0, 0x7FFFFFFF, 0x00020000);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_byte, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <class M, int BM, int TN, int MINW, int OUT>
 __global__ __launch_bounds__(256, MINW) void pair_kernel(
     const uint4 *__restrict__ qpl, const uint4 *__restrict__ tpl,
@@ -414,7 +425,14 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
         qsrc[k] = qpl + (size_t)(M::P0 + (e < QV ? sp : 0)) * q_ps + (size_t)c_begin * q_npad + i0 + sr;
         qdst0[k] = &qs[0][e < QV ? sp : 0][sr];
     }
-    const uint4 *tchunk = tpl + (size_t)M::P0 * t_ps + (size_t)c_begin * t_npad + j0 + threadIdx.x;
+    // column loads go through buffer descriptors: wave-uniform base in SGPRs (SALU arithmetic), the
+    // lane's byte offset in ONE constant VGPR per column -> no VALU address arithmetic in the loop
+    // (64-bit per-lane pointers cost two VALU adds per load, ~2 % of the issue slots)
+    const uint4 *tchunk = tpl + (size_t)M::P0 * t_ps + (size_t)c_begin * t_npad + j0;
+    uint32_t lane_byte[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+        lane_byte[tn] = (threadIdx.x + 256u * tn) * (uint32_t)sizeof(uint4);
 
     // prologue: first chunk of the row tile
 #pragma unroll
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-                tv[p][tn] = tchunk[(size_t)p * t_ps + 256 * tn];
+                tv[p][tn] = load_columns(tchunk + (size_t)p * t_ps, lane_byte[tn]);
         tchunk += t_npad;
 
 #pragma unroll
@@ -630,8 +648,8 @@ struct Variant {
 // [0] is the default: picked on MI355X with tools/kbench.py (profiles/r01/kbench_variants.txt)
 constexpr Variant kVarNHigh[] = {{24, 2, 4}, {16, 2, 4}, {32, 2, 3}};
 constexpr Variant kVarRaw[] = {{12, 2, 4}, {16, 2, 3}, {32, 2, 2}};
-constexpr Variant kVarK80[] = {{12, 2, 3}, {8, 2, 3}};
-constexpr Variant kVarTN93[] = {{12, 2, 3}, {8, 2, 4}, {16, 2, 2}};
+constexpr Variant kVarK80[] = {{8, 2, 3}, {12, 2, 3}};
+constexpr Variant kVarTN93[] = {{8, 2, 4}, {12, 2, 3}, {16, 2, 2}};
 
 template <class M, int BM, int TN, int MINW, int OUT>
 hipError_t launch_one(const PairLaunch &pl, hipStream_t stream)
