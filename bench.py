@@ -106,10 +106,16 @@ def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 1
     t0 = time.perf_counter()
     oracle.all_pairs_square(measure, codes_host, threads=cores, pair_range=(0, sample), native=native)
     dt = time.perf_counter() - t0
+    # and one thread, on a proportionally smaller sample (~2 s)
+    one = max(1, int(sample / dt * 2.0 / cores))
+    t1 = time.perf_counter()
+    oracle.all_pairs_square(measure, codes_host, threads=1, pair_range=(0, one), native=native)
+    dt1 = time.perf_counter() - t1
     return {"value": sample / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} canonical pairs of the same alignment ({n} x {codes_host.shape[1]} "
                       f"host slice), -m {measure}, {dt:.1f} s, oracle/distance_oracle.c "
-                      f"({'-O3 -march=native' if native else '-O2'}), {cores} threads"}
+                      f"({'-O3 -march=native' if native else '-O2'}), {cores} threads",
+            "value_1_thread": one / dt1, "sample_1_thread": f"first {one} pairs, {dt1:.1f} s"}
 
 
 def measured_traffic(name: str, variant: int):
