@@ -46,6 +46,11 @@ _SIGS = {
     "dst_set_variant": (C.c_int, [_vp, C.c_int]),
     "dst_variant_count": (C.c_int, [C.c_int]),
     "dst_set_ksplit": (C.c_int, [_vp, C.c_int]),
+    "dst_set_path": (C.c_int, [_vp, C.c_int]),
+    "dst_last_path": (C.c_int, [_vp]),
+    "dst_consensus": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "dst_differences": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _u64p]),
+    "dst_site_tallies": (C.c_int, [C.c_int, C.c_uint8, C.c_uint8, C.POINTER(C.c_int)]),
     "dst_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "dst_upload_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]),
     "dst_set_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

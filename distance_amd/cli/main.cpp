@@ -265,7 +265,7 @@ struct ParsedBlock {
 };
 
 ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool count_raw_upper, bool fixed_width,
-                        size_t width)
+                        size_t width, bool width_first)
 {
     ParsedBlock out;
     out.al = std::make_unique<Alignment>();
@@ -286,11 +286,11 @@ ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool cou
             out.stop = true;  // bio's Records iterator stops at an empty record
             break;
         }
-        if (first) {
-            al.width = rec.seq.size();
-            first = false;
-        } else if (rec.seq.size() != al.width) {
-            out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 188-190, 246-248
+        // stream_fasta() compares widths BEFORE encoding (src/fastaio.rs:246-254); load_fasta() encodes first
+        // (src/fastaio.rs:182) and compares afterwards (:186-190), so a loaded record that is both the wrong
+        // length and holds an invalid character reports the character.
+        if (width_first && rec.seq.size() != al.width) {
+            out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 246-248
             return out;
         }
         // encode() / encode_count_bases(): src/fastaio.rs:101-145
@@ -314,6 +314,15 @@ ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool cou
             al.counts.push_back(counting['T']);
             al.counts.push_back(counting['G']);
             al.counts.push_back(counting['C']);
+        }
+        if (!width_first) {
+            if (first) {
+                al.width = rec.seq.size();
+                first = false;
+            } else if (rec.seq.size() != al.width) {
+                out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 186-190
+                return out;
+            }
         }
         al.ids.push_back(rec.id);
         al.n += 1;
@@ -340,8 +349,8 @@ void parse_stream(FILE *fh, size_t block_bytes, size_t lookahead, const uint8_t 
                 break;
             }
             inflight.push_back(std::async(std::launch::async,
-                                          [b = std::move(block), table, count_raw_upper, width_known, w]() {
-                                              return parse_block(b, table, count_raw_upper, width_known, w);
+                                          [b = std::move(block), table, count_raw_upper, width_known, w, fixed_width]() {
+                                              return parse_block(b, table, count_raw_upper, width_known, w, fixed_width);
                                           }));
             block.clear();
         }
@@ -370,7 +379,10 @@ Alignment load_fasta(FILE *fh, const uint8_t *table, size_t threads)
 {
     Alignment al;
     bool first = true;
-    parse_stream(fh, (size_t)32 << 20, threads, table, false, false, 0, [&](std::unique_ptr<Alignment> part) {
+    // DISTANCE_PARSE_BLOCK_BYTES: test hook (tiny blocks put the records of a small file into different parse blocks)
+    const char *bb = std::getenv("DISTANCE_PARSE_BLOCK_BYTES");
+    const size_t block_bytes = bb && std::atol(bb) > 0 ? (size_t)std::atol(bb) : (size_t)32 << 20;
+    parse_stream(fh, block_bytes, threads, table, false, false, 0, [&](std::unique_ptr<Alignment> part) {
         if (part->n == 0)
             return;
         if (first) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -25,14 +26,23 @@ struct dst_ctx {
     struct Schedule {
         bool square = false;
         uint64_t rb = 0, re = 0, ncols = 0;
-        int bm = 0, bn = 0;
+        int bm = 0, bn = 0;  // dense tile shape; consensus-path tile lists: bm = rows per tile, bn = -1
         uint32_t nblocks = 0;
-        BlockDesc *d_blocks = nullptr;
+        void *d_blocks = nullptr;
         uint64_t last_use = 0;
     };
     std::vector<Schedule> schedules;
     uint64_t schedule_clock = 0;
     int variant = 0;
+    int path = DST_PATH_AUTO;         // dst_set_path
+    int last_path = DST_PATH_DENSE;   // what the most recent run used
+    // consensus path: tables, counters and scratch shared by the two sets
+    ConsensusLut *d_lut = nullptr;
+    unsigned long long *d_total = nullptr;
+    uint32_t *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    uint32_t *site_cur = nullptr;
+    size_t site_cur_bytes = 0;
     int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
     uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
     size_t scratch_bytes = 0;
@@ -85,11 +95,14 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    if (s.planes)
-        (void)hipFree(s.planes);
-    if (s.counts)
-        (void)hipFree(s.counts);
+    void *bufs[] = {s.planes, s.counts, s.ref.nib, s.ref.planes, s.ref.stats, s.rec.off, s.rec.ent,
+                    s.site.off, s.site.ent, s.aconst};
+    for (void *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    const uint64_t epoch = s.epoch;
     s = DeviceSet{};
+    s.epoch = epoch + 1;  // lists other sets hold against this set's reference are stale from now on
 }
 
 // (re)allocate the planes / counts of a set for n x len
@@ -99,11 +112,15 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     const size_t nchunks = std::max<size_t>(1, (len + kChunkSites - 1) / kChunkSites);
     const size_t npad = ((n + 256 + kPadRecords - 1) / kPadRecords) * kPadRecords;
     const size_t bytes = (size_t)PL_COUNT * nchunks * npad * sizeof(uint4);
-    if (!s.planes || s.planes_bytes < bytes || s.npad != npad || s.nchunks != nchunks) {
+    if (!s.planes || !s.counts || s.planes_bytes < bytes || s.npad != npad || s.nchunks != nchunks) {
         free_set(s);
         HIP_TRY(ctx, hipMalloc((void **)&s.planes, bytes ? bytes : 16));
         s.planes_bytes = bytes;
-        HIP_TRY(ctx, hipMalloc((void **)&s.counts, npad * 4 * sizeof(uint32_t)));
+        const hipError_t e = hipMalloc((void **)&s.counts, npad * 4 * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            free_set(s);  // never leave a set with planes but no counts behind
+            return fail_hip(ctx, e, "hipMalloc(base counts)");
+        }
     }
     s.n = n;
     s.len = len;
@@ -111,6 +128,9 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.npad = npad;
     s.loaded = false;
     s.have_counts = false;
+    s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
+    s.ref.valid = s.rec.valid = s.site.valid = false;
+    s.aconst_family = -1;
     return DST_OK;
 }
 
@@ -159,27 +179,43 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     return DST_OK;
 }
 
-int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t ncols, TileShape ts,
-                   hipStream_t stream, const BlockDesc **d_blocks, uint32_t *nblocks)
+// Tile lists already on the device, keyed by the launch geometry (no host sync or H2D on a hit).
+// bn >= 0: dense BlockDesc list of tile shape (bm, bn); bn == -1: consensus-path tiles of bm rows.
+int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t ncols, int bm, int bn,
+                     hipStream_t stream, const void **d_blocks, uint32_t *nblocks)
 {
     constexpr size_t kMaxSchedules = 16;
     for (auto &s : ctx->schedules) {
-        if (s.square == square && s.rb == rb && s.re == re && s.ncols == ncols && s.bm == ts.bm && s.bn == ts.bn) {
+        if (s.square == square && s.rb == rb && s.re == re && s.ncols == ncols && s.bm == bm && s.bn == bn) {
             s.last_use = ++ctx->schedule_clock;
             *d_blocks = s.d_blocks;
             *nblocks = s.nblocks;
             return DST_OK;
         }
     }
-    std::vector<BlockDesc> blocks = build_blocks(square, rb, re, ncols, ts);
+    std::vector<BlockDesc> blocks;
+    std::vector<ConsensusTile> tiles;
+    const void *src = nullptr;
+    size_t bytes = 0, count = 0;
+    if (bn >= 0) {
+        blocks = build_blocks(square, rb, re, ncols, TileShape{bm, bn});
+        src = blocks.data();
+        count = blocks.size();
+        bytes = count * sizeof(BlockDesc);
+    } else {
+        tiles = build_consensus_tiles(square, rb, re, ncols, (uint32_t)bm);
+        src = tiles.data();
+        count = tiles.size();
+        bytes = count * sizeof(ConsensusTile);
+    }
     dst_ctx::Schedule s;
     s.square = square;
     s.rb = rb;
     s.re = re;
     s.ncols = ncols;
-    s.bm = ts.bm;
-    s.bn = ts.bn;
-    s.nblocks = (uint32_t)blocks.size();
+    s.bm = bm;
+    s.bn = bn;
+    s.nblocks = (uint32_t)count;
     s.last_use = ++ctx->schedule_clock;
     if (ctx->schedules.size() >= kMaxSchedules) {
         // evict the least recently used; an in-flight kernel may still read it
@@ -192,16 +228,175 @@ int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t
             HIP_TRY(ctx, hipFree(ctx->schedules[victim].d_blocks));
         ctx->schedules.erase(ctx->schedules.begin() + (long)victim);
     }
-    if (!blocks.empty()) {
-        const size_t bytes = blocks.size() * sizeof(BlockDesc);
-        HIP_TRY(ctx, hipMalloc((void **)&s.d_blocks, bytes));
+    if (count) {
+        HIP_TRY(ctx, hipMalloc(&s.d_blocks, bytes));
         // pageable source: the copy is complete on return, later kernels on any stream see it
-        HIP_TRY(ctx, hipMemcpy(s.d_blocks, blocks.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(s.d_blocks, src, bytes, hipMemcpyHostToDevice));
     }
     ctx->schedules.push_back(s);
     *d_blocks = s.d_blocks;
     *nblocks = s.nblocks;
     return DST_OK;
+}
+
+int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t ncols, TileShape ts,
+                   hipStream_t stream, const BlockDesc **d_blocks, uint32_t *nblocks)
+{
+    const void *p = nullptr;
+    const int rc = prepare_schedule(ctx, square, rb, re, ncols, ts.bm, ts.bn, stream, &p, nblocks);
+    *d_blocks = static_cast<const BlockDesc *>(p);
+    return rc;
+}
+
+// =============================================================================================
+// consensus-delta path: reference, difference lists, path choice (kernels: dst_consensus.hip)
+// =============================================================================================
+constexpr uint64_t kMaxListEntries = 0x7FFFFFFFull;  // 32-bit CSR offsets
+constexpr uint32_t kConsensusRowsPerTile = 8;
+
+bool consensus_shape_ok(const DeviceSet &rows, const DeviceSet &cols)
+{
+    // list entries carry a site or a record in 28 bits next to the nibble
+    return rows.n < kEntryMask && cols.n < kEntryMask && rows.len < kEntryMask && rows.len == cols.len && rows.len > 0;
+}
+
+int ensure_lut(dst_ctx *ctx)
+{
+    if (ctx->d_lut)
+        return DST_OK;
+    auto lut = std::make_unique<ConsensusLut>();
+    build_consensus_lut(*lut);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_lut, sizeof(ConsensusLut)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lut, lut.get(), sizeof(ConsensusLut), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_total, sizeof(unsigned long long)));
+    return DST_OK;
+}
+
+// the reference sequence of `s` (plurality code per site over a sample of its records)
+int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
+{
+    if (s.ref.valid)
+        return DST_OK;
+    if (s.ref.nchunks != s.nchunks || !s.ref.nib) {
+        for (void *b : {(void *)s.ref.nib, (void *)s.ref.planes, (void *)s.ref.stats})
+            if (b)
+                HIP_TRY(ctx, hipFree(b));
+        s.ref.nib = nullptr;
+        s.ref.planes = nullptr;
+        s.ref.stats = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.nib, s.nchunks * kChunkSites));
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 4 * sizeof(uint64_t)));
+        s.ref.nchunks = s.nchunks;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 4 * sizeof(uint64_t), stream));
+    HIP_TRY(ctx, launch_ref_sample(s, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    s.ref.valid = true;
+    return DST_OK;
+}
+
+// Difference lists of `s` against the reference of `refset` (and, for a column set, the same entries by
+// site and panel).  DST_ERR_CAPACITY: more entries than 32-bit offsets hold — the caller runs dense.
+int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites, hipStream_t stream)
+{
+    const bool lists_ok = s.rec.valid && s.rec.ref_owner == &refset && s.rec.ref_epoch == refset.epoch;
+    if (lists_ok && (!want_sites || s.site.valid))
+        return DST_OK;
+    // other streams may still be reading the buffers about to be rebuilt
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    const uint32_t n_panels = (uint32_t)((s.n + kPanelCols - 1) / kPanelCols);
+    const size_t n_buckets = want_sites ? s.nchunks * kChunkSites * (size_t)n_panels : 0;
+    int rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.off, &s.site.off_cap, (n_buckets + 1) * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&ctx->site_cur, &ctx->site_cur_bytes, (n_buckets + 1) * sizeof(uint32_t));
+    if (!rc)
+        rc = ensure_bytes(ctx, (void **)&ctx->scan_tmp, &ctx->scan_tmp_bytes,
+                          scan_tmp_words(std::max(s.n + 1, n_buckets + 1)) * sizeof(uint32_t));
+    if (rc)
+        return rc;
+    s.rec.valid = false;
+    s.site.valid = false;
+    HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
+    if (want_sites)
+        HIP_TRY(ctx, hipMemsetAsync(s.site.off, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, false, want_sites, false, s.rec.off, nullptr, s.site.off, nullptr,
+                              nullptr, n_panels, ctx->d_total, stream));
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (total > kMaxListEntries)
+        return fail(ctx, DST_ERR_CAPACITY, "too many differences from the reference sequence for the consensus path");
+    s.rec.total = total;
+    rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, std::max<size_t>(total, 1) * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, std::max<size_t>(total, 1) * sizeof(uint32_t));
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
+    if (want_sites) {
+        HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->site_cur, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
+    }
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
+                              ctx->site_cur, s.site.ent, n_panels, ctx->d_total, stream));
+    // complete before the lists are published: later runs may be queued on other streams
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    s.rec.valid = true;
+    s.rec.ref_owner = &refset;
+    s.rec.ref_epoch = refset.epoch;
+    s.aconst_family = -1;
+    if (want_sites) {
+        s.site.valid = true;
+        s.site.n_panels = n_panels;
+    }
+    return DST_OK;
+}
+
+// A_k words of every record of `s` for (family, packing), summed from its current lists
+int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, bool wide, hipStream_t stream)
+{
+    if (s.aconst && s.aconst_family == family && s.aconst_wide == wide && s.aconst_epoch == s.epoch &&
+        s.aconst_ref_owner == &refset && s.aconst_ref_epoch == refset.epoch)
+        return DST_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());  // a run on another stream may still read the old words
+    int rc = ensure_bytes(ctx, (void **)&s.aconst, &s.aconst_cap, s.npad * kMaxWords * sizeof(uint32_t));
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, launch_aconst(s, refset.ref.nib, family, wide, ctx->d_lut, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    s.aconst_family = family;
+    s.aconst_wide = wide;
+    s.aconst_epoch = s.epoch;
+    s.aconst_ref_owner = &refset;
+    s.aconst_ref_epoch = refset.epoch;
+    return DST_OK;
+}
+
+// Which path is cheaper for this launch?  The sampled reference gives, per site, the fraction p_s of
+// records that deviate from it: a pair costs the dense path L sites whatever the data, and the consensus
+// path one output plus about sum_s p_s^2 intersection events.  Constants: measured on MI355X
+// (profiles/r02/consensus_calibration.txt), seconds.
+bool consensus_is_cheaper(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles)
+{
+    static const double dense_site_pairs_per_s[4] = {2.9e14, 1.95e14, 1.6e14, 1.45e14};
+    static const double out_s_per_pair[4] = {2.5e-12, 3.0e-12, 5e-12, 1.3e-11};
+    constexpr double event_s = 4e-11;
+    const int fam = family_of(measure);
+    const double S = (double)std::max<uint64_t>(cols.ref.h_stats[3], 1);
+    const double events_per_pair = (double)cols.ref.h_stats[2] / (S * S);
+    const double mean_list = (double)cols.ref.h_stats[1] / S;  // differences per record
+    const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[fam];
+    // building the lists reads the planes twice; walking a row's list costs one bucket lookup per panel
+    const double build = (rows.rec.valid && cols.site.valid) ? 0.0
+                                                              : (double)(rows.n + cols.n) * (double)cols.len * 1.5e-12 + 2e-4;
+    const double walk = (double)ntiles * kConsensusRowsPerTile * mean_list * 2e-9 / 256.0;
+    const double cons = (double)pairs * (out_s_per_pair[fam] + events_per_pair * event_s) + build + walk + 3e-5;
+    return cons < dense;
 }
 
 // the common run: rows [rb, re) of `rows` against every (square: later) record of `cols`
@@ -250,10 +445,78 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
         if (rc)
             return rc;
     }
+    // ---- path: consensus-delta (work ~ differences from a reference sequence) or dense bit-planes (work ~ L)
+    int rc = DST_OK;
+    bool use_consensus = false;
+    if (ctx->path != DST_PATH_DENSE && consensus_shape_ok(rows, cols)) {
+        rc = ensure_lut(ctx);
+        if (!rc)
+            rc = ensure_ref(ctx, cols, stream);
+        if (rc)
+            return rc;
+        const uint64_t n_panels = (cols.n + kPanelCols - 1) / kPanelCols;
+        const uint64_t tiles_est = std::max<uint64_t>(1, n_panels * ((re - rb + kConsensusRowsPerTile - 1) / kConsensusRowsPerTile) / (square ? 2 : 1));
+        use_consensus = ctx->path == DST_PATH_CONSENSUS ||
+                        consensus_is_cheaper(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu));
+        if (use_consensus) {
+            rc = ensure_index(ctx, cols, cols, true, stream);
+            if (!rc && &rows != &cols)
+                rc = ensure_index(ctx, rows, cols, false, stream);
+            if (rc == DST_ERR_CAPACITY)
+                use_consensus = false;  // denser than the lists can index: the dense path handles any input
+            else if (rc)
+                return rc;
+        }
+    }
+    if (use_consensus) {
+        const int fam = family_of(measure);
+        const bool wide = rows.len >= 65536;
+        rc = ensure_aconst(ctx, cols, cols, fam, wide, stream);
+        if (!rc && &rows != &cols)
+            rc = ensure_aconst(ctx, rows, cols, fam, wide, stream);
+        const void *d_tiles = nullptr;
+        uint32_t ntiles = 0;
+        if (!rc)
+            rc = prepare_schedule(ctx, square, rb, re, cols.n, (int)kConsensusRowsPerTile, -1, stream, &d_tiles, &ntiles);
+        if (rc)
+            return rc;
+        // F_k: every site where the reference is a known base adds f_k(base, base)
+        int unit[4];
+        site_tallies(measure, 136, 136, unit);
+        int64_t f[4];
+        for (int k = 0; k < 4; ++k)
+            f[k] = (int64_t)unit[k] * (int64_t)cols.ref.h_stats[0];
+        uint32_t f_words[kMaxWords];
+        pack_tallies(fam, wide, f, f_words);
+        ConsensusLaunch cl{};
+        cl.rows = &rows;
+        cl.cols = &cols;
+        cl.square = square;
+        cl.row_begin = rb;
+        cl.row_end = re;
+        cl.out_base = square ? square_row_start(cols.n, rb) : 0;
+        cl.out_kind = out_kind;
+        cl.d_out = d_out;
+        cl.d_tiles = static_cast<const ConsensusTile *>(d_tiles);
+        cl.ntiles = ntiles;
+        cl.wide = wide;
+        cl.d_lut = ctx->d_lut;
+        ctx->last_path = DST_PATH_CONSENSUS;
+        if (ntiles) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+            HIP_TRY(ctx, launch_consensus_pairs(measure, cl, f_words, stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+            ctx->timed_pair = true;
+        }
+        if (!stream_v)
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+        return DST_OK;
+    }
+    ctx->last_path = DST_PATH_DENSE;
     const TileShape ts = tile_shape(measure, ctx->variant);
     uint32_t nblocks = 0;
     const BlockDesc *d_blocks = nullptr;
-    int rc = prepare_blocks(ctx, square, rb, re, cols.n, ts, stream, &d_blocks, &nblocks);
+    rc = prepare_blocks(ctx, square, rb, re, cols.n, ts, stream, &d_blocks, &nblocks);
     if (rc)
         return rc;
     PairLaunch pl{};
@@ -423,6 +686,9 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
+    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur})
+        if (b)
+            (void)hipFree(b);
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
     if (ctx->scratch_free)
@@ -447,6 +713,16 @@ int dst_set_ksplit(dst_ctx *ctx, int ksplit)
     ctx->ksplit = ksplit;
     return DST_OK;
 }
+
+int dst_set_path(dst_ctx *ctx, int path)
+{
+    if (!ctx || path < DST_PATH_AUTO || path > DST_PATH_CONSENSUS)
+        return DST_ERR_ARG;
+    ctx->path = path;
+    return DST_OK;
+}
+
+int dst_last_path(const dst_ctx *ctx) { return ctx ? ctx->last_path : -1; }
 
 int dst_set_variant(dst_ctx *ctx, int variant)
 {
@@ -533,6 +809,140 @@ int dst_get_base_counts(dst_ctx *ctx, int slot, uint32_t *counts)
     HIP_TRY(ctx, hipMemcpyAsync(counts, s.counts, s.n * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DST_OK;
+}
+
+int dst_consensus(dst_ctx *ctx, int both_slots, uint8_t *cons, size_t cap)
+{
+    if (!ctx || !cons)
+        return DST_ERR_ARG;
+    DeviceSet &a = ctx->set[0];
+    if (!a.loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    const bool two = both_slots && ctx->set[1].loaded;
+    if (two && ctx->set[1].len != a.len)
+        return fail(ctx, DST_ERR_STATE, "Different length sequences in alignment(s)");
+    if (cap < a.len)
+        return fail(ctx, DST_ERR_CAPACITY, "consensus buffer shorter than the alignment");
+    if (a.len == 0)
+        return DST_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_hist = nullptr;
+    const size_t bytes = a.len * 3 * sizeof(uint32_t);
+    HIP_TRY(ctx, hipMalloc((void **)&d_hist, bytes));
+    std::vector<uint32_t> hist(a.len * 3);
+    hipError_t e = hipMemsetAsync(d_hist, 0, bytes, ctx->stream);
+    if (e == hipSuccess)
+        e = launch_site_hist(a, d_hist, ctx->stream);
+    if (e == hipSuccess && two)
+        e = launch_site_hist(ctx->set[1], d_hist, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(hist.data(), d_hist, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_hist);
+    if (e != hipSuccess)
+        return fail_hip(ctx, e, "consensus counts");
+    const uint64_t records = a.n + (two ? ctx->set[1].n : 0);
+    static const uint8_t back_translate[4] = {136, 72, 40, 24};  // [A, G, C, T], src/fastaio.rs:314-316
+    for (size_t i = 0; i < a.len; ++i) {
+        const uint64_t g = hist[3 * i], c = hist[3 * i + 1], t = hist[3 * i + 2];
+        const uint64_t counts[4] = {records - g - c - t, g, c, t};  // every non-G/C/T byte is looked up as A
+        size_t maxidx = 0;
+        uint64_t maxval = 0;
+        for (size_t k = 0; k < 4; ++k)
+            if (counts[k] > maxval) {  // strict: ties keep the earlier base (src/fastaio.rs:322-327)
+                maxval = counts[k];
+                maxidx = k;
+            }
+        cons[i] = back_translate[maxidx];
+    }
+    return DST_OK;
+}
+
+int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, uint64_t *offsets, uint32_t *sites,
+                    size_t cap_sites, uint64_t *total_out)
+{
+    if (!ctx || slot < 0 || slot > 1 || !offsets || !total_out || (len && !other))
+        return DST_ERR_ARG;
+    DeviceSet &s = ctx->set[slot];
+    if (!s.loaded)
+        return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    if (len != s.len) {
+        char msg[128];
+        std::snprintf(msg, sizeof msg, "Different length sequences in alignment(s): %zu vs %zu", len, s.len);
+        return fail(ctx, DST_ERR_STATE, msg);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_lut(ctx);
+    if (rc)
+        return rc;
+    // `other` as A, G, C, T planes (sites past len are N on both sides: never a difference)
+    std::vector<uint32_t> planes(4 * s.nchunks * 4, 0xFFFFFFFFu);
+    for (size_t i = 0; i < len; ++i)
+        for (int p = 0; p < 4; ++p)
+            if (!((other[i] >> (7 - p)) & 1u))
+                planes[(p * s.nchunks + i / kChunkSites) * 4 + (i % kChunkSites) / 32] &= ~(1u << (i % 32));
+    uint4 *d_ref = nullptr;
+    uint32_t *d_off = nullptr, *d_ent = nullptr, *d_tmp = nullptr;
+    std::vector<uint32_t> off32(s.n + 1);
+    unsigned long long total = 0;
+    hipError_t e = hipMalloc((void **)&d_ref, planes.size() * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_off, (s.n + 1) * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_tmp, scan_tmp_words(s.n + 1) * sizeof(uint32_t));
+    auto done = [&](int status) {
+        for (void *b : {(void *)d_ref, (void *)d_off, (void *)d_ent, (void *)d_tmp})
+            if (b)
+                (void)hipFree(b);
+        return status;
+    };
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_ref, planes.data(), planes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(d_off, 0, (s.n + 1) * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess)
+        e = launch_index(s, d_ref, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
+                         ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        return done(fail_hip(ctx, e, "differences (count)"));
+    if (total > kMaxListEntries)
+        return done(fail(ctx, DST_ERR_CAPACITY, "more than 2^31 differences"));
+    e = launch_exclusive_scan(d_off, s.n + 1, d_tmp, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(off32.data(), d_off, (s.n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        return done(fail_hip(ctx, e, "differences (scan)"));
+    for (size_t r = 0; r <= s.n; ++r)
+        offsets[r] = off32[r];
+    *total_out = total;
+    if (!sites)
+        return done(DST_OK);
+    if (cap_sites < total)
+        return done(fail(ctx, DST_ERR_CAPACITY, "sites buffer too small"));
+    if (total == 0)
+        return done(DST_OK);
+    e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = launch_index(s, d_ref, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, 1, ctx->d_total,
+                         ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        return done(fail_hip(ctx, e, "differences (fill)"));
+    for (uint64_t k = 0; k < total; ++k)
+        sites[k] &= kEntryMask;  // drop the nibble the pair kernel's lists carry
+    return done(DST_OK);
 }
 
 int dst_run_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, int out_kind,

@@ -120,6 +120,164 @@ std::vector<BlockDesc> build_blocks(bool square, uint64_t row_begin, uint64_t ro
     return out;
 }
 
+// ---- consensus-delta path: per-site semantics, tables, tiles ---------------------------------------
+
+int family_of(int measure)
+{
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH: return FAM_NHIGH;
+    case DST_RAW:
+    case DST_JC69: return FAM_RAW;
+    case DST_K80: return FAM_K80;
+    default: return FAM_TN93;
+    }
+}
+
+int family_words(int family, bool wide)
+{
+    const int nt = family == FAM_NHIGH ? 1 : family == FAM_RAW ? 2 : family == FAM_K80 ? 3 : 4;
+    return wide ? nt : (nt + 1) / 2;
+}
+
+// What ONE site adds to each tally: the bodies of the site loops of src/measures.rs.
+void site_tallies(int measure, uint8_t q, uint8_t t, int out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const bool same = (q & 8) == 8 && q == t;  // "are the bases certainly the same"
+    const bool differ = (q & t) < 16;          // "they are certainly different"
+    switch (measure) {
+    case DST_N:
+    case DST_N_HIGH:  // src/measures.rs:14-23 (and :28-53, which counts the same sites)
+        out[0] = differ;
+        break;
+    case DST_RAW:
+    case DST_JC69:  // src/measures.rs:59-66 -> {n, d}
+        if (same) {
+            out[1] = 1;
+        } else if (differ) {
+            out[0] = 1;
+            out[1] = 1;
+        }
+        break;
+    case DST_K80:  // src/measures.rs:85-107 -> {count_L, ts, tv}
+        if (same) {
+            out[0] = 1;
+        } else if (differ) {
+            const bool q_pur = (q & 55) == 0, t_pur = (t & 55) == 0, q_pyr = (q & 199) == 0, t_pyr = (t & 199) == 0;
+            if ((q_pur && t_pur) || (q_pyr && t_pyr)) {
+                out[1] = 1;
+                out[0] = 1;
+            } else if ((q_pur && t_pyr) || (q_pyr && t_pur)) {
+                out[2] = 1;
+                out[0] = 1;
+            }
+        }
+        break;
+    case DST_TN93:  // src/measures.rs:156-175 -> {count_L, count_d, count_P1, count_P2}
+        if (same) {
+            out[0] = 1;
+        } else if (differ && (q & 8) == 8 && (t & 8) == 8) {
+            out[1] = 1;
+            out[0] = 1;
+            if ((q | t) == 200)
+                out[2] = 1;
+            else if ((q | t) == 56)
+                out[3] = 1;
+        }
+        break;
+    default: break;
+    }
+}
+
+namespace {
+
+// the code src/encoding.rs gives a set of bases (high nibble): known bases carry bit 3, the N class is N itself
+uint8_t code_of_nibble(int nib)
+{
+    const bool one = nib == 8 || nib == 4 || nib == 2 || nib == 1;
+    return (uint8_t)(nib == 15 ? 240 : (nib << 4) | (one ? 8 : 0));
+}
+
+void pack_words(int family, bool wide, const int64_t d[4], uint32_t w[kMaxWords])
+{
+    const int nt = family == FAM_NHIGH ? 1 : family == FAM_RAW ? 2 : family == FAM_K80 ? 3 : 4;
+    for (int k = 0; k < kMaxWords; ++k)
+        w[k] = 0;
+    if (wide || nt == 1) {
+        for (int k = 0; k < nt; ++k)
+            w[k] = (uint32_t)d[k];
+        return;
+    }
+    // two tallies per word, exact modulo 2^32: word = low + 65536 * high
+    w[0] = (uint32_t)(d[0] + d[1] * 65536);
+    if (nt == 3)
+        w[1] = (uint32_t)d[2];
+    else if (nt == 4)
+        w[1] = (uint32_t)(d[2] + d[3] * 65536);
+}
+
+}  // namespace
+
+void pack_tallies(int family, bool wide, const int64_t d[4], uint32_t w[kMaxWords]) { pack_words(family, wide, d, w); }
+
+void build_consensus_lut(ConsensusLut &lut)
+{
+    static const int kFamilyMeasure[4] = {DST_N_HIGH, DST_RAW, DST_K80, DST_TN93};
+    static const int kRefNibble[kRefClasses] = {8, 4, 2, 1, 15};
+    std::memset(&lut, 0, sizeof lut);
+    for (int fam = 0; fam < 4; ++fam)
+        for (int wide = 0; wide < 2; ++wide) {
+            const int m = kFamilyMeasure[fam];
+            int kk[4];
+            site_tallies(m, 136, 136, kk);  // a known base against itself (the same for all four)
+            int64_t u[4] = {kk[0], kk[1], kk[2], kk[3]};
+            pack_words(fam, wide != 0, u, lut.unit[fam][wide]);
+            for (int cls = 0; cls < kRefClasses; ++cls) {
+                const uint8_t c = code_of_nibble(kRefNibble[cls]);
+                int fcc[4];
+                site_tallies(m, c, c, fcc);
+                for (int x = 1; x < 16; ++x) {
+                    const uint8_t qx = code_of_nibble(x);
+                    int fxc[4];
+                    site_tallies(m, qx, c, fxc);
+                    int64_t a[4];
+                    for (int k = 0; k < 4; ++k)
+                        a[k] = (int64_t)fxc[k] - fcc[k];
+                    pack_words(fam, wide != 0, a, lut.a[fam][wide][cls][x]);
+                    for (int y = 1; y < 16; ++y) {
+                        const uint8_t ty = code_of_nibble(y);
+                        int fxy[4], fcy[4];
+                        site_tallies(m, qx, ty, fxy);
+                        site_tallies(m, c, ty, fcy);
+                        int64_t h[4];
+                        for (int k = 0; k < 4; ++k)
+                            h[k] = (int64_t)fxy[k] - fxc[k] - fcy[k] + fcc[k];
+                        pack_words(fam, wide != 0, h, lut.h[fam][wide][cls][x][y]);
+                    }
+                }
+            }
+        }
+}
+
+// Tiles of one consensus-path launch: panel-major, so the workgroups in flight share a panel's site
+// buckets; rows that cannot pair with any column of a panel (square: i >= its last column) are left out.
+std::vector<ConsensusTile> build_consensus_tiles(bool square, uint64_t row_begin, uint64_t row_end,
+                                                 uint64_t n_cols, uint32_t rows_per_tile)
+{
+    std::vector<ConsensusTile> out;
+    if (row_end <= row_begin || n_cols == 0 || rows_per_tile == 0)
+        return out;
+    const uint64_t n_panels = (n_cols + kPanelCols - 1) / kPanelCols;
+    for (uint64_t p = 0; p < n_panels; ++p) {
+        const uint64_t last = std::min<uint64_t>(n_cols, (p + 1) * kPanelCols) - 1;  // last column of the panel
+        const uint64_t r_end = square ? std::min(row_end, last) : row_end;
+        for (uint64_t i0 = row_begin; i0 < r_end; i0 += rows_per_tile)
+            out.push_back({(uint32_t)i0, (uint32_t)std::min<uint64_t>(r_end, i0 + rows_per_tile), (uint32_t)p});
+    }
+    return out;
+}
+
 }  // namespace dst
 
 // ================================================================================================
@@ -143,6 +301,17 @@ int dst_measure_from_name(const char *name)
 }
 
 int dst_tally_width(int measure) { return tally_width(measure); }
+
+int dst_site_tallies(int measure, uint8_t q, uint8_t t, int *out)
+{
+    if (measure < DST_N || measure > DST_TN93 || !out)
+        return DST_ERR_ARG;
+    int o[4];
+    site_tallies(measure, q, t, o);
+    for (int k = 0; k < tally_width(measure); ++k)
+        out[k] = o[k];
+    return DST_OK;
+}
 
 const char *dst_status_string(int status)
 {

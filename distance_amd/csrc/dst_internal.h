@@ -36,6 +36,48 @@ constexpr uint32_t kChunkSites = 128;  // sites per uint4
 constexpr uint32_t kPadRecords = 512;  // npad granularity (>= every tile's BN)
 constexpr uint32_t kBlockThreads = 256;
 
+// ---- consensus-delta path (dst_consensus.hip) -------------------------------------------------
+// Every tally of every measure is a sum over sites of a per-site function f_k(q[s], t[s]) of the two
+// codes' high nibbles (src/measures.rs:14-23, 56-66, 85-107, 156-175).  Against a reference sequence c
+// (a per-site plurality code: the idea of consensus(), src/fastaio.rs:289-336, and of snp_consensus(),
+// src/measures.rs:28-53, carried to every measure):
+//     T_k(q,t) = F_k + A_k(q) + A_k(t) + sum over sites where BOTH q and t differ from c of h_k
+//     F_k    = sum_s f_k(c,c)              A_k(x) = sum over x's difference sites of f_k(x,c) - f_k(c,c)
+//     h_k    = f_k(q,t) - f_k(q,c) - f_k(c,t) + f_k(c,c)
+// exact integers whatever c is; the work is proportional to the differences from c, not to L.
+constexpr uint32_t kPanelCols = 8192;      // column records per site bucket = width of the LDS accumulators
+constexpr uint32_t kEntryShift = 28;       // list entries: (site or record) | nibble << 28
+constexpr uint32_t kEntryMask = (1u << kEntryShift) - 1;
+constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
+constexpr int kMaxWords = 4;               // packed accumulator words per pair
+
+struct ConsensusRef {             // the reference sequence, sampled from the set that owns it
+    uint8_t *nib = nullptr;       // [nchunks * 128] nibble per site (8, 4, 2, 1 or 15; 15 beyond len)
+    uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records')
+    uint64_t *stats = nullptr;    // device: {known sites, sum of deviants, sum of deviants^2, sample size}
+    uint64_t h_stats[4] = {0, 0, 0, 0};
+    size_t nchunks = 0;
+    bool valid = false;
+};
+
+struct RecordIndex {              // per record: the sites where it differs from the reference, ascending
+    uint32_t *off = nullptr;      // [n + 1]
+    uint32_t *ent = nullptr;      // site | nibble << 28
+    size_t off_cap = 0, ent_cap = 0;
+    uint64_t total = 0;
+    const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
+    uint64_t ref_epoch = 0;
+    bool valid = false;
+};
+
+struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
+    uint32_t *off = nullptr;      // [n_sites * n_panels + 1]
+    uint32_t *ent = nullptr;      // record | nibble << 28 (any order inside a bucket)
+    size_t off_cap = 0, ent_cap = 0;
+    uint32_t n_panels = 0;
+    bool valid = false;
+};
+
 struct DeviceSet {
     uint4 *planes = nullptr;      // PL_COUNT * nchunks * npad
     uint32_t *counts = nullptr;   // npad x 4 {A,T,G,C}
@@ -43,6 +85,17 @@ struct DeviceSet {
     size_t n = 0, len = 0, nchunks = 0, npad = 0;
     bool loaded = false;
     bool have_counts = false;
+    uint64_t epoch = 0;           // bumped by every upload: stale consensus indexes are rebuilt
+    // consensus path
+    ConsensusRef ref;
+    RecordIndex rec;
+    SiteIndex site;
+    uint32_t *aconst = nullptr;   // [kMaxWords][npad] packed A_k words of one measure family (see the key below)
+    size_t aconst_cap = 0;
+    int aconst_family = -1;       // what `aconst` currently holds: family, packing, and the lists it was summed from
+    bool aconst_wide = false;
+    uint64_t aconst_epoch = 0, aconst_ref_epoch = 0;
+    const void *aconst_ref_owner = nullptr;
 };
 
 struct BlockDesc {
@@ -67,6 +120,62 @@ struct PairLaunch {
     uint32_t nblocks;
     uint32_t ksplit = 1;          // > 1: split-L launch, partial tallies added atomically
 };
+
+struct ConsensusTile {
+    uint32_t i0, i1, panel;  // rows [i0, i1) against column panel `panel`
+};
+
+// per-measure-family tables of the consensus path, built on the host (dst_host.cpp) from the per-site
+// semantics of src/measures.rs and uploaded once per context
+struct ConsensusLut {
+    // [family][wide][ref class][row nibble][col nibble][word]   h_k packed like the accumulators
+    // [family][wide][ref class][nibble][word]                    A-term of one difference site
+    // [family][wide][word]                                       f_k(known, same known) = F per known ref site
+    uint32_t h[4][2][kRefClasses][16][16][kMaxWords];
+    uint32_t a[4][2][kRefClasses][16][kMaxWords];
+    uint32_t unit[4][2][kMaxWords];
+};
+enum Family : int { FAM_NHIGH = 0, FAM_RAW = 1, FAM_K80 = 2, FAM_TN93 = 3 };
+int family_of(int measure);
+int family_words(int family, bool wide);       // accumulator words per pair
+void build_consensus_lut(ConsensusLut &lut);   // dst_host.cpp
+void pack_tallies(int family, bool wide, const int64_t tallies[4], uint32_t words[kMaxWords]);
+// the per-site tallies of one code pair (bytes as src/encoding.rs produces them): the site loop bodies of
+// src/measures.rs:14-23, 56-66, 85-107, 156-175.  out has tally_width(measure) entries.
+void site_tallies(int measure, uint8_t q, uint8_t t, int out[4]);
+std::vector<ConsensusTile> build_consensus_tiles(bool square, uint64_t row_begin, uint64_t row_end,
+                                                 uint64_t n_cols, uint32_t rows_per_tile);
+
+struct ConsensusLaunch {
+    const DeviceSet *rows;
+    const DeviceSet *cols;
+    bool square;
+    uint64_t row_begin, row_end, out_base;
+    int out_kind;
+    void *d_out;
+    const ConsensusTile *d_tiles;
+    uint32_t ntiles;
+    bool wide;                   // one 32-bit word per tally (alignments of 65,536 sites or more)
+    const ConsensusLut *d_lut;
+};
+
+// ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
+hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
+// count pass (fill == false): rec_cnt[n], site_cnt[len * n_panels] (when want_sites), *total
+// fill pass: entries behind the scanned offsets.  ref_planes: [4][nchunks] uint4.
+hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, bool fill, bool want_sites, bool skip_nclass,
+                        uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_off_or_cnt, uint32_t *site_cur,
+                        uint32_t *site_ent, uint32_t n_panels, unsigned long long *total, hipStream_t stream);
+// in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
+size_t scan_tmp_words(size_t n);
+hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
+hipError_t launch_aconst(const DeviceSet &set, const uint8_t *ref_nib, int family, bool wide, const ConsensusLut *d_lut,
+                         hipStream_t stream);
+// f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
+hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
+                                  hipStream_t stream);
+// exact per-site counts of known G, C, T over the records of `set`, added into hist[len][3]
+hipError_t launch_site_hist(const DeviceSet &set, uint32_t *hist, hipStream_t stream);
 
 // ---- kernel launchers (dst_kernels.hip) -----------------------------------------------------
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,

@@ -17,6 +17,7 @@ MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
 FLOAT_MEASURES = ("raw", "jc69", "k80", "tn93")
 OUT_DISTANCE, OUT_TALLY, OUT_TALLY16 = 0, 1, 2
+PATHS = {"auto": 0, "dense": 1, "consensus": 2}
 
 
 def _measure_id(measure) -> int:
@@ -141,13 +142,43 @@ class Engine:
         """0 = automatic split over L for launches with few tiles, 1 = off, k = force."""
         self._check(self._lib.dst_set_ksplit(self._h, ksplit))
 
+    def set_path(self, path):
+        """"auto" (default), "dense" (bit-plane tiles, work ~ L) or "consensus" (difference lists against a
+        per-site plurality sequence: the idea of the reference's -m n, src/measures.rs:28-53, for every measure)."""
+        self._check(self._lib.dst_set_path(self._h, PATHS[path] if isinstance(path, str) else int(path)))
+
+    def last_path(self) -> str:
+        return {1: "dense", 2: "consensus"}.get(self._lib.dst_last_path(self._h), "?")
+
+    # ---- per-alignment precompute of -m n (src/lib.rs:223-231) ------------------------------
+    def consensus(self, both_slots: bool = False) -> np.ndarray:
+        """consensus() of src/fastaio.rs:289-336 over slot 0 (and slot 1), computed on the device."""
+        _, length = self.set_info(0)
+        out = np.zeros(length, np.uint8)
+        self._check(self._lib.dst_consensus(self._h, int(both_slots), out.ctypes.data, out.nbytes))
+        return out
+
+    def differences(self, slot: int, other: np.ndarray) -> list[np.ndarray]:
+        """get_differences() of src/fastaio.rs:67-75 for every record of `slot` against `other`."""
+        n, _ = self.set_info(slot)
+        other = np.ascontiguousarray(other, np.uint8)
+        offsets = np.zeros(n + 1, np.uint64)
+        total = C.c_uint64()
+        self._check(self._lib.dst_differences(self._h, slot, other.ctypes.data, other.size, offsets.ctypes.data,
+                                              None, 0, C.byref(total)))
+        sites = np.zeros(max(total.value, 1), np.uint32)
+        self._check(self._lib.dst_differences(self._h, slot, other.ctypes.data, other.size, offsets.ctypes.data,
+                                              sites.ctypes.data, sites.size, C.byref(total)))
+        return [sites[int(offsets[r]):int(offsets[r + 1])] for r in range(n)]
+
     # ---- input -----------------------------------------------------------------------------
     def upload(self, slot: int, codes: np.ndarray, base_counts: np.ndarray | None = None):
         """codes: (n, L) uint8 Paradis codes (any row stride); base_counts: (n, 4) {A,T,G,C}."""
         codes = np.asarray(codes)
         if codes.dtype != np.uint8 or codes.ndim != 2:
             raise ValueError("codes must be a 2-D uint8 array")
-        if codes.shape[1] and codes.strides[1] != 1:
+        # rows must run forwards in memory, at least one row apart (a reversed view has a negative stride)
+        if codes.shape[1] and (codes.strides[1] != 1 or (codes.shape[0] > 1 and codes.strides[0] < codes.shape[1])):
             codes = np.ascontiguousarray(codes)
         stride = codes.strides[0] if codes.shape[0] > 1 else max(codes.shape[1], 1)
         bc = None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DST_ABI_VERSION 1
+#define DST_ABI_VERSION 2
 
 typedef struct dst_ctx dst_ctx;
 
@@ -91,6 +91,23 @@ int dst_variant_count(int measure);
  * (exact).  0 = automatic (default: launches with fewer than 1,024 tiles), 1 = never split, k > 1 = force. */
 int dst_set_ksplit(dst_ctx *ctx, int ksplit);
 
+/* Which kernels a run uses.  Both give the same integers (tallies bit-exact, the same finalisation):
+ *  DST_PATH_DENSE:     bit-plane tile kernels, work ~ pairs x L whatever the data (src/measures.rs:14-23,
+ *                      56-66, 85-107, 156-175 evaluated at every site).
+ *  DST_PATH_CONSENSUS: the idea of the reference's `-m n` (snp_consensus, src/measures.rs:28-53, over the
+ *                      difference lists of get_differences(), src/fastaio.rs:67-75, against consensus(),
+ *                      src/fastaio.rs:289-336) carried to every measure: tallies from each record's
+ *                      differences to a per-site plurality sequence; work ~ pairs + the differences two
+ *                      records share.  Low-diversity alignments (SARS-CoV-2-like) run output-bound.
+ *                      Shapes its lists cannot index (zero-width alignments, 2^28 or more records or sites,
+ *                      more than 2^31 differences in a set) run dense even when this is selected.
+ *  DST_PATH_AUTO:      (default) per launch, whichever a sampled estimate of the alignment's diversity
+ *                      says is faster. */
+typedef enum { DST_PATH_AUTO = 0, DST_PATH_DENSE = 1, DST_PATH_CONSENSUS = 2 } dst_path;
+int dst_set_path(dst_ctx *ctx, int path);
+/* DST_PATH_DENSE or DST_PATH_CONSENSUS: what the most recent run on this context used */
+int dst_last_path(const dst_ctx *ctx);
+
 /* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */
 /* codes: row-major n x len Paradis bytes, rows row_stride bytes apart (>= len).
  * base_counts: n x 4 {A, T, G, C} per-record counts for tn93 (src/fastaio.rs:53-66, or the
@@ -105,6 +122,19 @@ int dst_upload_device(dst_ctx *ctx, int slot, const void *d_codes, size_t n, siz
 int dst_set_info(const dst_ctx *ctx, int slot, size_t *n, size_t *len);
 /* per-record {A,T,G,C} counts the device holds for `slot` (n x 4), copied to host */
 int dst_get_base_counts(dst_ctx *ctx, int slot, uint32_t *counts);
+
+/* ---- per-alignment precompute of `-m n` (src/lib.rs:223-231) ------------------------------ */
+/* consensus(), src/fastaio.rs:289-336, computed on the device: per site the plurality of A, G, C, T over
+ * every record of slot 0 (and of slot 1 too when both_slots != 0 and it is loaded — the reference walks every
+ * loaded file), every other code counted as A, ties to the first of A, G, C, T.  cons receives len codes
+ * (136 / 72 / 40 / 24). */
+int dst_consensus(dst_ctx *ctx, int both_slots, uint8_t *cons, size_t cap);
+/* get_differences(), src/fastaio.rs:67-75, for every record of `slot` against `other` (len codes, host
+ * memory; normally the consensus): ascending sites with seq[i] < 240 && seq[i] != other[i].  CSR output:
+ * offsets has n + 1 entries, sites holds offsets[n] entries.  Pass sites == NULL to get offsets / *total only;
+ * DST_ERR_CAPACITY when cap_sites < *total. */
+int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, uint64_t *offsets, uint32_t *sites,
+                    size_t cap_sites, uint64_t *total);
 
 /* ---- canonical order helpers (src/lib.rs:502-596) --------------------------------------- */
 uint64_t dst_square_pairs(uint64_t n);                   /* n(n-1)/2 */
@@ -168,6 +198,11 @@ int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *
 int dst_plan_tiles(int square, uint64_t row_begin, uint64_t row_end, uint64_t n_cols, int measure,
                    int variant, uint32_t *ij, size_t cap_tiles, size_t *count, int *tile_rows,
                    int *tile_cols);
+
+/* What ONE site contributes to each tally of `measure` for the code pair (q, t): the bodies of the site loops
+ * of src/measures.rs:14-23, 56-66, 85-107, 156-175 (out has dst_tally_width(measure) entries, each 0 or 1).
+ * Pure host code; the consensus path's tables are built from it. */
+int dst_site_tallies(int measure, uint8_t q, uint8_t t, int *out);
 
 /* ---- host finalisation in the reference's f64 operation order --------------------------- */
 /* tallies: dst_tally_width(measure) uint32 per pair.  q_counts/t_counts: {A,T,G,C} of record_1 /

@@ -101,6 +101,16 @@ def test_set_up_errors_before_any_gpu_work(tmp_path):
     empty.write_text("")
     r = run([str(empty)])                 # src/fastaio.rs:97-99
     assert r.returncode == 1 and b"Empty FASTA file" in r.stderr
+    # load_fasta() encodes a record before it compares widths (src/fastaio.rs:182-190): a record that is both
+    # too short and holds an invalid character reports the character — also when it sits in a later parse block
+    both = tmp_path / "both.fasta"
+    both.write_text(">a\nACGT\n>b\nACX\n")
+    r = run([str(both)])
+    assert r.returncode == 1 and b"Invalid nucleotide character in record 'b': 'X'" in r.stderr
+    later = tmp_path / "later.fasta"
+    later.write_text(">a\nACGT\n>b\nACGT\n>c\nAX\n")
+    r = subprocess.run([CLI, str(later)], capture_output=True, env=dict(os.environ, DISTANCE_PARSE_BLOCK_BYTES="6"))
+    assert r.returncode == 1 and b"Invalid nucleotide character in record 'c': 'X'" in r.stderr
 
 
 def test_block_parallel_parser_matches_the_sequential_reader():

@@ -187,6 +187,11 @@ def test_single_record_and_error_paths_with_gpu(tmp_path):
     bad.write_text(">s1\nACGT\n>s2\nAC*T\n")
     r = subprocess.run([CLI, "-i", str(a), "-s", str(bad)], capture_output=True)
     assert r.returncode == 1 and b"Invalid nucleotide character in record 's2': '*'" in r.stderr
+    # stream_fasta() compares widths BEFORE encoding (src/fastaio.rs:246-254): short + invalid reports the width
+    both = tmp_path / "both.fasta"
+    both.write_text(">s1\nACGT\n>s2\nA*T\n")
+    r = subprocess.run([CLI, "-i", str(a), "-s", str(both)], capture_output=True)
+    assert r.returncode == 1 and b"Different length sequences in alignment(s): 3 vs 4" in r.stderr
     empty = tmp_path / "empty.fasta"
     empty.write_text("")
     r = subprocess.run([CLI, "-i", str(a), "-s", str(empty)], capture_output=True)  # src/fastaio.rs:281-283

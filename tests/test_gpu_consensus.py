@@ -1,0 +1,243 @@
+"""GPU (-m gpu): the consensus-delta path (dst_consensus.hip) and the per-alignment precompute of `-m n`
+(consensus(), src/fastaio.rs:289-336; get_differences(), src/fastaio.rs:67-75) against the oracle.
+The general parity suite (test_gpu_parity.py, test_gpu_fuzz.py) already runs every case on this path;
+here are the shapes that are specific to it: panels of 8,192 columns, lists longer than one slice,
+32-bit tallies, shared gap runs, the path choice."""
+import numpy as np
+import pytest
+
+import distance_amd as da
+import oracle
+from helpers import CODES, random_alignment, uniform_codes
+
+pytestmark = pytest.mark.gpu
+ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = da.Engine(0)
+    yield e
+    e.close()
+
+
+def low_diversity(n, L, seed, subs=3e-3, p_n=2e-3, p_amb=3e-4, gap_rows=0.05):
+    """SARS-CoV-2-like: one root, sparse substitutions, sparse N / IUPAC codes, shared terminal gap runs."""
+    rng = np.random.default_rng(seed)
+    root = rng.choice(np.array([136, 72, 40, 24], np.uint8), size=L)
+    codes = np.tile(root, (n, 1))
+    m = rng.random((n, L)) < subs
+    codes[m] = rng.choice(np.array([136, 72, 40, 24], np.uint8), size=int(m.sum()))
+    m = rng.random((n, L)) < p_n
+    codes[m] = rng.choice(CODES[14:], size=int(m.sum()))
+    m = rng.random((n, L)) < p_amb
+    codes[m] = rng.choice(CODES[4:14], size=int(m.sum()))
+    for r in np.nonzero(rng.random(n) < gap_rows)[0]:
+        codes[r, : rng.integers(0, min(L, 60) + 1)] = 244
+        codes[r, L - rng.integers(0, min(L, 60) + 1):] = 244
+    return np.ascontiguousarray(codes)
+
+
+def sample_check(eng, codes, measure, pairs, counts=None):
+    """tallies bit-exact and distances within 1e-12 on sampled (i, j) of the square run"""
+    n = len(codes)
+    om = "n_high" if measure == "n" else measure
+    by_row = {}
+    for i, j in pairs:
+        by_row.setdefault(int(i), []).append(int(j))
+    for i, js in by_row.items():
+        tl = eng.run_square(measure, i, i + 1, tallies=True)
+        d = eng.run_square(measure, i, i + 1)
+        for j in js:
+            assert list(tl[j - i - 1]) == [int(x) for x in oracle.tallies(om, codes[i], codes[j])], (measure, i, j)
+            want = oracle.pair_distance(om, codes[i], codes[j])
+            got = d[j - i - 1]
+            assert (np.isnan(want) and np.isnan(got)) or got == want or abs(got - want) <= 1e-12, (measure, i, j)
+
+
+def test_paths_agree_bit_for_bit_and_report_themselves(eng):
+    codes = low_diversity(700, 3000, 1)
+    eng.upload(0, codes)
+    for m in ALL:
+        eng.set_path("dense")
+        td, dd = eng.run_square(m, tallies=True), eng.run_square(m)
+        assert eng.last_path() == "dense"
+        eng.set_path("consensus")
+        tc, dc = eng.run_square(m, tallies=True), eng.run_square(m)
+        assert eng.last_path() == "consensus"
+        assert np.array_equal(td, tc), m
+        assert np.array_equal(dd, dc, equal_nan=True), m       # same device finalisation on the same tallies
+        t16 = eng.run_square(m, tallies16=True)
+        assert np.array_equal(t16.astype(np.uint32), tc), m
+    eng.set_path("auto")
+
+
+def test_column_panels_and_row_tiles(eng):
+    """More than two panels of 8,192 column records; rows that start inside a panel; partial last panel."""
+    n, L = 17000, 400
+    codes = low_diversity(n, L, 2, subs=5e-3)
+    eng.set_path("consensus")
+    eng.upload(0, codes)
+    rng = np.random.default_rng(4)
+    rows = [0, 1, 7, 8, 8190, 8191, 8192, 8193, 16383, 16384, 16385, n - 2] + [int(x) for x in rng.integers(0, n - 1, 12)]
+    pairs = []
+    for i in rows:
+        cols = {i + 1, n - 1, min(n - 1, max(i + 1, 8191)), min(n - 1, max(i + 1, 8192)),
+                min(n - 1, max(i + 1, 16384))} | {int(x) for x in rng.integers(i + 1, n, 6)}
+        pairs += [(i, j) for j in cols]
+    for m in ("n_high", "raw", "tn93", "k80"):
+        sample_check(eng, codes, m, pairs)
+    assert eng.last_path() == "consensus"
+    # the whole triangle agrees with the dense path (tallies, 144M pairs would be too many: compare a row band)
+    band = (8100, 8300)
+    tc = eng.run_square("raw", *band, tallies=True)
+    eng.set_path("dense")
+    assert np.array_equal(eng.run_square("raw", *band, tallies=True), tc)
+    eng.set_path("auto")
+
+
+def test_long_lists_and_dense_columns(eng):
+    """Rows whose list is longer than one 256-entry slice; sites where most records deviate from the
+    plurality (bucket sizes in the thousands); a record that is all N."""
+    n, L = 1500, 2600
+    codes = low_diversity(n, L, 3)
+    rng = np.random.default_rng(5)
+    for r in (0, 3, 700, 1499):                      # ~60 % of the sites differ: lists of ~1,500 entries
+        m = rng.random(L) < 0.6
+        codes[r, m] = rng.choice(CODES, size=int(m.sum()))
+    codes[5, :] = 240
+    codes[6, :] = 244
+    for s in (0, 17, 1300, L - 1):                   # 45 % minor allele at a few sites
+        m = rng.random(n) < 0.45
+        codes[m, s] = 24 if codes[0, s] != 24 else 72
+    eng.set_path("consensus")
+    eng.upload(0, codes)
+    for m in ALL:
+        want = oracle.all_pairs_square(m, codes)
+        got = eng.run_square(m)
+        if m in da.INT_MEASURES:
+            assert np.array_equal(got, want.astype(np.int64)), m
+        else:
+            ok = np.isclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
+            assert ok.all(), (m, int((~ok).sum()))
+    assert eng.last_path() == "consensus"
+    eng.set_path("auto")
+
+
+def test_wide_tallies_for_long_alignments(eng):
+    """65,536 sites or more: one 32-bit word per tally (up to four words per pair, 128 KiB of LDS)."""
+    L = 70001
+    a = low_diversity(40, L, 6, subs=2e-2, p_n=1e-2)
+    b = low_diversity(9, L, 7, subs=2e-2, p_n=1e-2)
+    a[3, :] = a[4, :]                                 # identical pair: tallies reach L
+    eng.set_path("consensus")
+    eng.upload(0, a)
+    eng.upload(1, b)
+    for m in ALL:
+        om = "n_high" if m == "n" else m
+        tl = eng.run_square(m, tallies=True)
+        ij = oracle.pairs_square(len(a))
+        for k in range(0, len(ij), 7):
+            i, j = int(ij[k][0]), int(ij[k][1])
+            assert list(tl[k]) == [int(x) for x in oracle.tallies(om, a[i], a[j])], (m, i, j)
+        rect = eng.run_rect(m, tallies=True)          # rows: slot 0, columns: slot 1 (its own reference)
+        stream = eng.run_rect(m, row_slot=1, col_slot=0, tallies=True)
+        for i in (0, 3, 39):
+            for j in (0, 8):
+                want = [int(x) for x in oracle.tallies(om, a[i], b[j])]
+                assert list(rect[i, j]) == want and list(stream[j, i]) == want, (m, i, j)
+        assert eng.last_path() == "consensus"
+    assert int(eng.run_square("tn93", 3, 4, tallies=True)[0][0]) > 65535
+    eng.set_path("auto")
+
+
+def test_rectangle_and_stream_against_another_sets_reference(eng):
+    """Two files / stream mode: the rows' lists are taken against the COLUMN set's reference, also when the
+    two sets have different plurality codes at many sites."""
+    L = 900
+    a = low_diversity(300, L, 8)
+    b = low_diversity(70, L, 9)                       # another root: differs from a's at ~3/4 of the sites
+    eng.set_path("consensus")
+    eng.upload(0, a)
+    eng.upload(1, b)
+    for m in ALL:
+        want = oracle.all_pairs_rect(m, a, b)
+        for got in (eng.run_rect(m), eng.run_rect(m, row_slot=1, col_slot=0).T):
+            if m in da.INT_MEASURES:
+                assert np.array_equal(got, want.astype(np.int64)), m
+            else:
+                assert np.isclose(got, want, rtol=0, atol=1e-12, equal_nan=True).all(), m
+    # re-uploading the column set invalidates the rows' lists (they were relative to its old reference)
+    b2 = low_diversity(70, L, 10)
+    eng.upload(1, b2)
+    assert np.array_equal(eng.run_rect("n_high"), oracle.all_pairs_rect("n_high", a, b2).astype(np.int64))
+    assert np.array_equal(eng.run_square("n_high"), oracle.all_pairs_square("n_high", a).astype(np.int64))
+    eng.set_path("auto")
+
+
+def test_auto_picks_by_diversity(eng):
+    eng.set_path("auto")
+    low = low_diversity(3000, 6000, 11)
+    eng.upload(0, low)
+    d_low = eng.run_square("raw")
+    assert eng.last_path() == "consensus"
+    high = uniform_codes(3000, 6000, 12)              # every code equally likely: nothing to gain from lists
+    eng.upload(0, high)
+    eng.run_square("raw", 0, 64)
+    assert eng.last_path() == "dense"
+    eng.upload(0, low)
+    eng.set_path("dense")
+    assert np.array_equal(eng.run_square("raw"), d_low, equal_nan=True)
+    eng.set_path("auto")
+
+
+def test_consensus_matches_fastaio(eng, golden):
+    """dst_consensus against the oracle's consensus(): non-ACGT counted as A, ties to the first of A,G,C,T,
+    one and two loaded sets; and the reference's own fixture (src/fastaio.rs:431-453)."""
+    for seed, n, L in ((1, 1, 40), (2, 2, 300), (3, 57, 1000), (4, 2100, 333)):
+        a = uniform_codes(n, L, seed) if seed % 2 else random_alignment(n, L, seed, p_gap=0.3)
+        b = random_alignment(max(1, n // 2), L, seed + 100, p_ambig=0.2)
+        eng.upload(0, a)
+        eng.upload(1, b)
+        assert np.array_equal(eng.consensus(), oracle.consensus(a)), seed
+        assert np.array_equal(eng.consensus(both_slots=True), oracle.consensus(a, b)), seed
+    for v in golden["consensus"]:
+        recs = np.stack([oracle.encode(s.encode()) for s in v["rows"]])
+        eng.upload(0, recs)
+        assert eng.consensus().tolist() == v["codes"]
+
+
+def test_differences_match_fastaio(eng, golden):
+    """dst_differences against get_differences(): ascending sites, N / - / ? never listed."""
+    for seed, n, L in ((1, 3, 15), (2, 40, 1000), (3, 9, 5000)):
+        a = random_alignment(n, L, seed, p_gap=0.1, p_ambig=0.05, divergence=0.1)
+        eng.upload(0, a)
+        cons = oracle.consensus(a)
+        for other in (cons, a[0], np.full(L, 240, np.uint8)):
+            got = eng.differences(0, other)
+            for r in range(n):
+                assert np.array_equal(got[r].astype(np.uint64), oracle.get_differences(a[r], other)), (seed, r)
+    for v in golden["get_differences"]:
+        q, t = oracle.encode(v["seq"].encode()), oracle.encode(v["other"].encode())
+        eng.upload(0, np.stack([q]))
+        assert eng.differences(0, t)[0].tolist() == v["differences"]
+
+
+def test_n_equals_the_sparse_walk_of_the_reference(eng):
+    """C1's shape, complete: 100 x 10,000 `-m n` on both paths against snp_consensus() walked over the
+    oracle's consensus and difference lists (src/measures.rs:28-53)."""
+    from tools import synth
+    codes = synth.alignment(synth.SEED ^ 1, 100, 10_000)
+    cons = oracle.consensus(codes)
+    diffs = [oracle.get_differences(r, cons) for r in codes]
+    want = np.array([oracle.pair_distance("n", codes[int(i)], codes[int(j)], q_diffs=diffs[int(i)], t_diffs=diffs[int(j)])
+                     for i, j in oracle.pairs_square(100)], np.int64)
+    eng.upload(0, codes)
+    for path in ("dense", "consensus", "auto"):
+        eng.set_path(path)
+        assert np.array_equal(eng.run_square("n"), want), path
+    # the device's own precompute gives the same lists the walk used
+    assert np.array_equal(eng.consensus(), cons)
+    dev = eng.differences(0, cons)
+    assert all(np.array_equal(dev[r].astype(np.uint64), diffs[r]) for r in range(100))
+    eng.set_path("auto")

@@ -1,5 +1,5 @@
-"""GPU (-m gpu): seeded randomised sweep over shapes, measures, modes, row ranges, tile variants
-and split-L factors — integer tallies bit-exact against the oracle, device distances within 1e-12,
+"""GPU (-m gpu): seeded randomised sweep over shapes, measures, modes, row ranges, kernel paths (dense
+bit-planes / consensus-delta), tile variants and split-L factors — integer tallies bit-exact against the oracle, device distances within 1e-12,
 host-finalised distances bit-identical."""
 import math
 
@@ -58,6 +58,7 @@ def test_randomised_parity_sweep():
                 m = str(m)
                 eng.set_variant(int(rng.integers(0, lib.dst_variant_count(da.MEASURES[m]))))
                 eng.set_ksplit(int(rng.choice([0, 0, 1, 3, 16])))
+                eng.set_path(str(rng.choice(["dense", "consensus", "consensus", "auto"])))
                 om = "n_high" if m == "n" else m
                 if not two:
                     rb = int(rng.integers(0, n))

@@ -16,9 +16,12 @@ TOL = 1e-12
 ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["dense", "consensus"])
+def eng(request):
+    """Every parity test runs on both kernel families: the dense bit-plane tiles and the consensus-delta path."""
     e = da.Engine(0)
+    e.set_path(request.param)
+    e.path_name = request.param
     yield e
     e.close()
 
@@ -344,6 +347,12 @@ def test_strided_and_unaligned_rows(eng):
     eng.upload(0, view)
     want = oracle.all_pairs_square("raw", np.ascontiguousarray(view))
     assert_close(eng.run_square("raw"), want)
+    rev = big[::-1]                            # negative row stride: copied, never passed as a huge size_t
+    eng.upload(0, rev)
+    assert_close(eng.run_square("raw"), oracle.all_pairs_square("raw", np.ascontiguousarray(rev)))
+    bcast = np.broadcast_to(big[0], (4, 1000)) # row stride 0
+    eng.upload(0, bcast)
+    assert np.array_equal(eng.run_square("n_high"), np.zeros(6, np.int64))
 
 
 def test_upload_from_device_memory_aligned_and_unaligned(eng):

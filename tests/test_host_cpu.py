@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/distance_hip.h but not exported"
-    assert lib.dst_abi_version() == 1
+    assert lib.dst_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -131,3 +131,54 @@ def test_format_distance_matches_rust_display():
         assert da.format_distance("raw", v) == oracle.format_distance(v)
     assert da.format_distance("n", 12345) == "12345"
     assert da.format_distance("raw", -0.0) == "-0.000000000000"
+
+
+# ---- consensus-delta path: host-side pieces -------------------------------------------------------
+def _site(measure, q, t):
+    out = (C.c_int * 4)()
+    assert da.load().dst_site_tallies(da.MEASURES[measure], int(q), int(t), out) == 0
+    return list(out)[:oracle.N_TALLIES[measure]]
+
+
+def test_site_tallies_match_the_oracle_on_every_code_pair():
+    """dst_site_tallies (the table generator of the consensus path) against the oracle's one-site tallies
+    for all 17 x 17 ordered code pairs of every measure."""
+    from helpers import CODES
+    for m in ("n", "n_high", "raw", "jc69", "k80", "tn93"):
+        for q in CODES:
+            for t in CODES:
+                want = oracle.tallies(m, np.array([q], np.uint8), np.array([t], np.uint8))
+                assert _site(m, q, t) == [int(x) for x in want], (m, q, t)
+                assert _site(m, q, t) == _site(m, t, q)          # every per-site function is symmetric
+
+
+def test_consensus_delta_identity_reproduces_the_tallies():
+    """T(q,t) = F + A(q) + A(t) + sum over shared difference sites of h, for ANY reference sequence:
+    evaluated in numpy from dst_site_tallies and compared with the oracle's site loops."""
+    from helpers import CODES, random_alignment, uniform_codes
+    rng = np.random.default_rng(3)
+    for codes in (random_alignment(7, 240, 5, divergence=0.05), uniform_codes(5, 120, 6)):
+        n, L = codes.shape
+        for ref in (oracle.consensus(codes), rng.choice(CODES, size=L),       # consensus, arbitrary codes,
+                    np.full(L, 240, np.uint8)):                               # all N
+            for m in ("n_high", "raw", "k80", "tn93"):
+                w = oracle.N_TALLIES[m]
+                f = {(int(a), int(b)): np.array(_site(m, a, b)) for a in CODES for b in CODES}
+                F = sum(f[(int(c), int(c))] for c in ref)
+                A = [sum((f[(int(x), int(c))] - f[(int(c), int(c))] for x, c in zip(row, ref) if (x >> 4) != (c >> 4)),
+                         np.zeros(w, int)) for row in codes]
+                for i in range(n):
+                    for j in range(i + 1, n):
+                        tot = F + A[i] + A[j]
+                        for s in range(L):
+                            x, y, c = int(codes[i, s]), int(codes[j, s]), int(ref[s])
+                            if (x >> 4) != (c >> 4) and (y >> 4) != (c >> 4):
+                                tot = tot + f[(x, y)] - f[(x, c)] - f[(c, y)] + f[(c, c)]
+                        assert list(tot) == [int(v) for v in oracle.tallies(m, codes[i], codes[j])], (m, i, j)
+
+
+def test_consensus_tiles_cover_every_pair_once():
+    """(not exported: checked through the pair counts the tile builder's geometry implies)"""
+    lib = da.load()
+    for n in (1, 2, 8191, 8192, 8193, 20000):
+        assert lib.dst_square_pairs(n) == n * (n - 1) // 2
