@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — all-pairs genetic-distance throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3raw|C3|C2|C5|C4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over the whole synthetic alignment, starting from the
-row-major N x L Paradis byte matrix resident in HBM: bit-plane pack -> pair-tile kernel ->
-finalise to f64 distances in canonical order (-> for N>1, every rank's slab sent straight to
-rank 0 over RCCL).  Prints ONE JSON line (rank 0).  `value` = pairs of the whole job / step time.
+One "step" = one pass of the hot path over the whole synthetic alignment, starting from the row-major
+N x L Paradis byte matrix resident in HBM: bit-plane pack -> (difference lists) -> pair kernel -> f64
+distances in canonical order in HBM (-> for N>1, every rank's slab sent straight to rank 0 over RCCL).
+Prints ONE JSON line (rank 0).  `value` = pairs of the whole job / step time, on the library's default
+path choice (DST_PATH_AUTO); the line also carries, each timed over the same steps/warmup:
+  legs.dense      the same measure with the dense bit-plane kernels forced (VALU-issue roofline),
+  legs.tn93*      the C3 measure (the metric is "raw+tn93"), default path and dense,
+  cpu_baseline(s) the oracle on the host cores for raw / tn93 / n_high / n (sparse walk) and the C1 line.
 
 Default workload: 50,000 x 30,000, -m raw — the shape the north-star target is quoted on.
+Synthetic data: SURVEY §8(d)'s generator (tools/synth: xoshiro256**, seed 0xD157A2CE ^ config id).
 """
 from __future__ import annotations
 
@@ -30,72 +35,38 @@ import torch.distributed as dist
 
 import distance_amd as da
 from distance_amd.multi import chunked_layout, post_chunk, root_share, slab_layout
+from tools import synth
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
 HBM_COPY_GBS = 6290.0
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes x clock
 
 WORKLOADS = {
-    # name: (n, L, measure) — BASELINE.json configs
-    "C2": (10_000, 30_000, "raw"),
-    "C3": (50_000, 30_000, "tn93"),
-    "C3raw": (50_000, 30_000, "raw"),     # north-star target kernel at the C3 shape (default)
-    "C5": (200_000, 1_000, "jc69"),
+    # name: (n, L, measure, config id of BASELINE.json) — the all-pairs configs
+    "C2": (10_000, 30_000, "raw", 2),
+    "C3": (50_000, 30_000, "tn93", 3),
+    "C3raw": (50_000, 30_000, "raw", 3),   # north-star target kernel at the C3 shape (default)
+    "C5": (200_000, 1_000, "jc69", 5),
+    "C4": (1_000, 5_000_000, "n_high", 4),  # loaded set; streamed batches: see bench_c4()
 }
-OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  # VALU ops / 32 sites
-# Measured issue ceiling of the raw step (1 v_and + 4 v_bitop3 + 2 v_bcnt on VGPRs only, 8 waves/SIMD,
+OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  # dense path: VALU ops / 32 sites
+# Measured issue ceiling of the dense raw step (1 v_and + 4 v_bitop3 + 2 v_bcnt on VGPRs only, 8 waves/SIMD,
 # no memory traffic): tools/ubench/ifetch.hip / order.hip, profiles/r01/ubench_rawstep.txt
 RAW_STEP_CEILING_NS = 10.6
 
 
-def synth_alignment(n: int, L: int, seed: int, device) -> torch.Tensor:
-    """SURVEY §8d synthetic alignment as Paradis codes, generated on the GPU in row chunks:
-    root with P(A,C,G,T)=(.30,.18,.20,.32); per-site substitution rate 1/1000 per record
-    (~Poisson(L/1000) per record); N w.p. 1e-3; 2-/3-fold IUPAC code w.p. 1e-4; 1 % of records
-    get leading and trailing '-' runs of U[0,200] sites."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    base = torch.tensor([136, 40, 72, 24], dtype=torch.uint8, device=device)          # A C G T
-    iupac = torch.tensor([192, 160, 144, 96, 80, 48, 224, 176, 208, 112], dtype=torch.uint8, device=device)
-    probs = torch.tensor([0.30, 0.18, 0.20, 0.32], device=device)
-    root_idx = torch.multinomial(probs, L, replacement=True, generator=g)
-    codes = torch.empty((n, L), dtype=torch.uint8, device=device)
-    chunk = max(1, min(n, (256 << 20) // max(L, 1)))
-    pos = torch.arange(L, device=device)
-    for r0 in range(0, n, chunk):
-        r1 = min(n, r0 + chunk)
-        rows = r1 - r0
-        u = torch.rand((rows, L), device=device, generator=g)
-        idx = root_idx.expand(rows, L)
-        shift = torch.randint(1, 4, (rows, L), device=device, generator=g, dtype=torch.int64)
-        idx = torch.where(u < 1e-3, (idx + shift) % 4, idx)
-        c = base[idx]
-        u2 = torch.rand((rows, L), device=device, generator=g)
-        c = torch.where(u2 < 1e-3, torch.full_like(c, 240), c)
-        amb = iupac[torch.randint(0, 10, (rows, L), device=device, generator=g)]
-        c = torch.where((u2 >= 1e-3) & (u2 < 1.1e-3), amb, c)
-        gap_rows = torch.rand(rows, device=device, generator=g) < 0.01
-        lead = torch.randint(0, 201, (rows,), device=device, generator=g) * gap_rows
-        trail = torch.randint(0, 201, (rows,), device=device, generator=g) * gap_rows
-        gap = (pos[None, :] < lead[:, None]) | (pos[None, :] >= (L - trail)[:, None])
-        c = torch.where(gap, torch.full_like(c, 244), c)
-        codes[r0:r1] = c
-        del u, u2, idx, shift, c, amb, gap
-    return codes
-
-
-def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 12.0) -> dict:
-    """The oracle (restated reference algorithm, C, pthreads) timed on this box's host cores on a
-    bounded sample of the same workload: the leading pairs of the canonical order."""
-    import oracle
-    # the GPU box grants a CPU share of 16 threads per GPU: size the pool to that, not to the host
+def host_threads() -> int:
+    # the GPU box grants a CPU share of 16 threads per GPU: size pools to that, not to the host
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = int(os.environ.get("DST_BENCH_THREADS", min(avail, 16)))
-    try:
-        oracle.build(native=True)
-        native = True
-    except Exception:
-        native = False
+    return int(os.environ.get("DST_BENCH_THREADS", min(avail, 16)))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the oracle (restated reference algorithm, C, pthreads) on this box's host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float, cores: int, native: bool) -> dict:
+    """A bounded sample of the same workload: the leading pairs of the canonical order."""
+    import oracle
     n = codes_host.shape[0]
     total = n * (n - 1) // 2
     t0 = time.perf_counter()
@@ -106,52 +77,80 @@ def cpu_baseline(codes_host: np.ndarray, measure: str, target_seconds: float = 1
     t0 = time.perf_counter()
     oracle.all_pairs_square(measure, codes_host, threads=cores, pair_range=(0, sample), native=native)
     dt = time.perf_counter() - t0
-    # and one thread, on a proportionally smaller sample (~2 s)
-    one = max(1, int(sample / dt * 2.0 / cores))
-    t1 = time.perf_counter()
-    oracle.all_pairs_square(measure, codes_host, threads=1, pair_range=(0, one), native=native)
-    dt1 = time.perf_counter() - t1
-    return {"value": sample / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    note = " (includes the consensus + difference-list precompute of the host slice, src/lib.rs:223-231)" if measure == "n" else ""
+    return {"value": sample / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "measure": measure,
             "sample": f"first {sample} canonical pairs of the same alignment ({n} x {codes_host.shape[1]} "
                       f"host slice), -m {measure}, {dt:.1f} s, oracle/distance_oracle.c "
-                      f"({'-O3 -march=native' if native else '-O2'}), {cores} threads",
-            "value_1_thread": one / dt1, "sample_1_thread": f"first {one} pairs, {dt1:.1f} s"}
+                      f"({'-O3 -march=native' if native else '-O2'}), {cores} threads{note}"}
 
 
-def measured_traffic(name: str, variant: int):
-    """HBM bytes per pair-kernel launch from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
+def cpu_baselines(codes_host: np.ndarray, measure: str) -> tuple[dict, list]:
+    import oracle
+    cores = host_threads()
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    main = cpu_baseline(codes_host, measure, 8.0, cores, native)
+    one = cpu_baseline(codes_host[:2000], measure, 2.0, 1, native)
+    main["value_1_thread"] = one["value"]
+    main["sample_1_thread"] = one["sample"]
+    others = []
+    for m in ("raw", "tn93", "n_high", "n"):
+        if m != measure:
+            others.append(cpu_baseline(codes_host, m, 4.0, cores, native))
+    # C1 (BASELINE.json configs[0]): 100 x 10,000, -m n, ONE thread — the reference's own CPU-runnable case
+    c1 = synth.alignment(synth.SEED ^ 1, 100, 10_000)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        oracle.all_pairs_square("n", c1, threads=1, native=native)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    others.append({"value": 4950 / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "measure": "n",
+                   "sample": f"C1 complete: 100 x 10,000, -m n (consensus + difference lists + sparse walk), "
+                             f"4,950 pairs in {dt * 1e3:.2f} ms, mean of {reps} runs, 1 thread"})
+    return main, others
+
+
+def measured_traffic(name: str, kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
     FETCH_SIZE x 1024 x 2 (gfx950 under-count of 16-B/lane streaming reads, MI355X_MICROARCH.md §HBM)
-    + WRITE_SIZE x 1024), or None when this workload/variant was not profiled."""
+    + WRITE_SIZE x 1024), or None when this workload was not profiled.  Latest round wins."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
         try:
             for rec in json.load(open(path)):
-                if rec["workload"] == name and rec["variant"] == variant and rec["kernel"] == "pair_kernel":
+                if rec["workload"] == name and rec["kernel"] == kernel:
                     best = rec
         except Exception:
             pass
     return best
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3raw", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override record count")
     ap.add_argument("--len", type=int, default=0, help="override alignment width")
     ap.add_argument("--measure", default="", help="override measure")
-    ap.add_argument("--variant", type=int, default=0, help="pair-kernel tile variant")
+    ap.add_argument("--path", default="auto", choices=["auto", "dense", "consensus"], help="kernel path of the main leg")
+    ap.add_argument("--variant", type=int, default=0, help="dense pair-kernel tile variant")
     ap.add_argument("--chunks", type=int, default=8, help="N>1: sub-slabs per rank (send k overlaps compute k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements")
-    ap.add_argument("--seed", type=int, default=0xD157A2CE)
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra timed legs (dense path, tn93)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=synth.SEED)
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="debug: N ranks share GPU 0 and exchange over gloo via host staging (checks the "
                          "multi-rank indexing on a 1-GPU box; RCCL itself needs one GPU per rank)")
-    ap.add_argument("--verify", action="store_true", help="rank 0 re-computes sampled rows and compares")
+    ap.add_argument("--verify", action="store_true", help="rank 0 re-computes sampled rows and compares (always on for N>1)")
     ap.add_argument("--wire-f64", action="store_true", help="N>1: always send 8-byte results, never uint16 tallies")
+    ap.add_argument("--batch", type=int, default=64, help="C4: streamed records per batch")
+    ap.add_argument("--batches", type=int, default=8, help="C4: streamed batches per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,48 +172,185 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "C4":
+        from tools.bench_c4 import bench_c4
+        return bench_c4(args, rank, world, dev, dev_index)
 
-    n, L, measure = WORKLOADS[args.workload]
+    n, L, measure, config_id = WORKLOADS[args.workload]
     n = args.n or n
     L = args.len or L
     measure = args.measure or measure
     total_pairs = n * (n - 1) // 2
+    stock = not (args.n or args.len or args.measure)
 
-    # All GPU work (torch's generator / gather and the engine's kernels) runs on ONE explicit
-    # non-default stream: a NULL stream handle means "the context's own stream" to the C ABI.
+    # All GPU work (the H2D of the synthetic set and the engine's kernels) runs on ONE explicit non-default
+    # stream: a NULL stream handle means "the context's own stream" to the C ABI.
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     assert stream != 0
-    codes = synth_alignment(n, L, args.seed, dev)      # every rank: the full replicated set
+    host_codes = synth.alignment(args.seed ^ config_id, n, L, threads=host_threads())   # every rank: the full set
+    codes = torch.from_numpy(host_codes).to(dev)
+    if rank != 0 or args.no_cpu_baseline:
+        host_codes = host_codes[:1]
     eng = da.Engine(dev_index)
     eng.set_variant(args.variant)
+    eng.set_path(args.path)
+    out_dtype = torch.int64 if measure in da.INT_MEASURES else torch.float64
+    width = da.tally_width(measure)
 
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------------------------------------
+    # N = 1: one engine, the whole triangle per step
+    # ---------------------------------------------------------------------------------------------
+    def single_gpu_leg(m: str, path: str, out: torch.Tensor) -> dict:
+        eng.set_path(path)
+
+        def step():
+            eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+            eng.run_square_device(m, 0, n, out.data_ptr(), out.numel() * 8, stream=stream)
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        pair_ms, pack_ms = [], []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            ms = eng.last_kernel_ms()     # HIP events recorded on the launch stream
+            pair_ms.append(ms["pair_ms"])
+            pack_ms.append(ms["pack_ms"])
+        fence()
+        elapsed = time.perf_counter() - t0
+        used = eng.last_path()
+        k_ms = float(np.mean(pair_ms))
+        leg = {"measure": m, "path_requested": path, "path_used": used, "ms_per_step": 1e3 * elapsed / args.steps,
+               "pairs_per_s": total_pairs / (elapsed / args.steps), "steps": args.steps, "warmup": args.warmup,
+               "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms,
+                              "lists_and_constants": max(0.0, 1e3 * elapsed / args.steps - k_ms - float(np.mean(pack_ms)))}}
+        leg["roofline"] = roofline(m, used, k_ms, total_pairs)
+        return leg
+
+    def roofline(m: str, used: str, k_ms: float, launch_pairs: int) -> dict:
+        words = (L + 127) // 128 * 4
+        logical = launch_pairs * (2 * L + 8)
+        hbm_logical = {"bytes_per_launch": logical, "GBps": logical / (k_ms * 1e-3) / 1e9,
+                       "x_hbm_peak": logical / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "SURVEY 8(d) contract figure: pairs x (2L read + 8 written) as if every pair streamed both "
+                               "rows from HBM; both paths reuse operands on chip, so this is not a bound (kept for reference)"}
+        if used == "dense":
+            lane_ops = launch_pairs * words * OPS_PER_WORD[m] / (k_ms * 1e-3)
+            kernel = "pair_kernel"
+            r = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
+                 "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": kernel, "kernel_ms": k_ms,
+                 "ops_per_32_sites": OPS_PER_WORD[m],
+                 "ns_per_32site_step_per_simd": k_ms * 1e6 / (launch_pairs * words / 65536.0),
+                 "measured_issue_ceiling_ns": RAW_STEP_CEILING_NS if m in ("raw", "jc69") else None,
+                 "frac_of_measured_issue_ceiling": (RAW_STEP_CEILING_NS / (k_ms * 1e6 / (launch_pairs * words / 65536.0))
+                                                    if m in ("raw", "jc69") else None),
+                 "note": "useful VALU lane-ops (5..8 per 32 sites per pair) against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; "
+                         "v_bcnt_u32_b32 issues at half rate on gfx950, so the reachable ceiling of this instruction mix "
+                         "is the pure-register microbenchmark figure beside it"}
+        else:
+            # consensus path: the compulsory HBM traffic of one launch is the result itself (8 B per pair, written
+            # once) plus the per-record constants and difference lists (read once; ~1e-3 of the writes)
+            nbytes = launch_pairs * 8 + n * 4 * 8 + int(n * max(1.0, L / 1000.0 * 2.2)) * 8
+            kernel = "consensus_pair_kernel"
+            r = {"bound": "hbm", "achieved": nbytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "kernel_ms": k_ms,
+                 "algorithmic_bytes_per_launch": nbytes,
+                 "frac_of_measured_copy_rate": nbytes / (k_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                 "note": "algorithmic bytes = 8 B of result per pair written once + per-record constants and difference "
+                         "lists read once (DESIGN.md 3); the kernel's floor is the HBM write of the N^2/2 results"}
+        tr = measured_traffic(args.workload if stock and m == measure else ("C3" if stock and args.workload == "C3raw" and m == "tn93" else ""), kernel)
+        r["traffic"] = tr["hbm_bytes_per_launch"] if tr and world == 1 else None
+        r["traffic_source"] = (tr["source"] + " — replayed from profiles/, not measured in this run") if tr and world == 1 else None
+        r["hbm_logical"] = hbm_logical
+        return r
+
+    if world == 1:
+        full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
+        legs = {}
+        main_leg = single_gpu_leg(measure, args.path, full_out)
+        if not args.no_extra:
+            if main_leg["path_used"] != "dense":
+                legs["dense"] = single_gpu_leg(measure, "dense", full_out)
+            if stock and args.workload == "C3raw":
+                legs["tn93"] = single_gpu_leg("tn93", args.path, full_out)
+                if legs["tn93"]["path_used"] != "dense":
+                    legs["tn93_dense"] = single_gpu_leg("tn93", "dense", full_out)
+            eng.set_path(args.path)
+        result = {
+            "metric": "pairwise comparisons/sec",
+            "value": main_leg["pairs_per_s"],
+            "unit": "pairs/s",
+            "n_gpus": 1,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": main_leg["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order)",
+                       "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs,
+                       "path": main_leg["path_used"], "path_requested": args.path,
+                       "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
+                       "variant": args.variant},
+            "roofline": main_leg["roofline"],
+            "kernels_ms": main_leg["kernels_ms"],
+            "site_compares_per_s": main_leg["pairs_per_s"] * L,
+            "legs": legs,
+        }
+        if args.verify:
+            result["verify"] = verify_rows(eng, codes, full_out, n, L, measure, [0, 1, n // 3, n // 2, n - 2], dev_index, stream)
+        if not args.no_cpu_baseline:
+            base, others = cpu_baselines(host_codes[:min(n, 8000)], measure)
+            result["cpu_baseline"] = base
+            result["cpu_baselines"] = others
+        print(json.dumps(result))
+        eng.close()
+        return
+
+    # ---------------------------------------------------------------------------------------------
+    # N > 1: contiguous canonical ranges, sub-slabs sent to rank 0 while the next one is computed
+    # ---------------------------------------------------------------------------------------------
     # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
     # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
     # same device arithmetic as a direct run); k80: 6 B.  tn93 (4 tallies = 8 B) travels as f64.
-    width = da.tally_width(measure)
-    wire16 = world > 1 and L < 65536 and 2 * width < 8 and not args.wire_f64
-    # rank 0 also finalises every pair it receives (HBM-bound: 2*width B read + 8 B written at
-    # ~4.5 TB/s) — it gets a correspondingly smaller share of the pair space
+    wire16 = L < 65536 and 2 * width < 8 and not args.wire_f64
+    # rank 0 also finalises every pair it receives (HBM-bound: 2*width B read + 8 B written at ~4.5 TB/s),
+    # so it gets a smaller share of the pair space.  The pair rate that sizes the share is MEASURED here: every
+    # rank times one run of an equal-split slab on the path it will use, the mean goes to all ranks.
     first_share = None
     if wire16:
-        pair_rate = {"raw": 6.3e9, "jc69": 6.3e9, "k80": 5.5e9, "n": 9.5e9, "n_high": 9.5e9}[measure] * 30000.0 / max(L, 1)
+        eq_bounds, eq_offs = slab_layout(n, world, square=True)
+        probe_pairs = eq_offs[rank + 1] - eq_offs[rank]
+        probe = torch.empty((max(probe_pairs, 1), 2 * width), dtype=torch.uint8, device=dev)
+        eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run_square_device(measure, eq_bounds[rank], eq_bounds[rank + 1], probe.data_ptr(), probe.numel(),
+                                  stream=stream, out_kind=da.OUT_TALLY16)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        rate = torch.tensor([probe_pairs / max(dt, 1e-9)], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
+        dist.all_reduce(rate)
+        pair_rate = float(rate.item()) / world
         first_share = root_share(world, (2 * width + 8) / 4.5e12 * pair_rate)
+        del probe
     bounds, offsets = slab_layout(n, world, square=True, first_share=first_share)
-    rb, re = bounds[rank], bounds[rank + 1]
     my_pairs = offsets[rank + 1] - offsets[rank]
-    out_dtype = torch.int64 if measure in da.INT_MEASURES else torch.float64
-    # N>1: each rank's range is cut into sub-slabs; sub-slab k is on its way to rank 0 (RCCL
-    # send/recv on RCCL's own stream) while sub-slab k+1 is being computed.
-    chunks = args.chunks if world > 1 else 1
+    chunks = args.chunks
     sub_rows, sub_offs = chunked_layout(n, world, chunks, first_share=first_share)
     # (the uint16 tallies travel as raw bytes: NCCL/RCCL has no 16-bit unsigned type)
-    if world == 1:
-        full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
-        local_out = full_out
-        wire_local = wire_full = None
-    elif rank == 0:
+    if rank == 0:
         full_out = torch.empty(total_pairs, dtype=out_dtype, device=dev)
         local_out = full_out[offsets[0]:offsets[1]]          # rank 0 computes straight into place
         wire_local = None
@@ -225,7 +361,6 @@ def main():
         wire_local = torch.empty((max(my_pairs, 1), 2 * width), dtype=torch.uint8, device=dev) if wire16 else None
         wire_full = None
     base = offsets[rank]
-
     staged = []
 
     def rehearse_chunk(k):
@@ -254,16 +389,15 @@ def main():
                                     full_out.data_ptr() + 8 * lo, 8 * (hi - lo), tally_kind=da.OUT_TALLY16,
                                     stream=stream)
 
-    # N>1: sub-slab launches alternate between two streams, so the draining tail of launch k
-    # overlaps the ramp-up of launch k+1 (each launch alone is only a few waves of tiles deep)
-    sub_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if world > 1 else [work_stream]
+    # sub-slab launches alternate between two streams, so the draining tail of launch k overlaps the
+    # ramp-up of launch k+1 (each launch alone is only a few waves of tiles deep)
+    sub_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
     def step():
         eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
         works = []
         for s_ in sub_streams:
-            if s_ is not work_stream:
-                s_.wait_stream(work_stream)          # the pack above feeds every sub-slab
+            s_.wait_stream(work_stream)          # the pack above feeds every sub-slab
         for k in range(chunks):
             r0, r1 = sub_rows[rank][k], sub_rows[rank][k + 1]
             lo, hi = sub_offs[rank][k] - base, sub_offs[rank][k + 1] - base
@@ -275,20 +409,19 @@ def main():
                 elif hi > lo:
                     eng.run_square_device(measure, r0, r1, local_out.data_ptr() + 8 * lo, 8 * (hi - lo),
                                           stream=ks.cuda_stream)
-                if world > 1 and not args.rehearse_gloo:
+                if not args.rehearse_gloo:
                     works.append(post_chunk(wire_local if wire16 else local_out, wire_full if wire16 else full_out,
                                             sub_offs, k, dst=0))
-                elif world > 1:
+                else:
                     works.append(rehearse_chunk(k))
         for s_ in sub_streams:
-            if s_ is not work_stream:
-                work_stream.wait_stream(s_)          # the next step's pack must not overtake them
+            work_stream.wait_stream(s_)          # the next step's pack must not overtake them
         for k, ws in enumerate(works):
             for w in ws:
                 w.wait()
             if wire16 and rank == 0 and not args.rehearse_gloo:
                 finalize_received(k)
-        if world > 1 and args.rehearse_gloo and rank == 0:
+        if args.rehearse_gloo and rank == 0:
             for (lo, hi), t in staged:
                 (wire_full if wire16 else full_out)[lo:hi].copy_(t)
             staged.clear()
@@ -296,118 +429,77 @@ def main():
                 for k in range(chunks):
                     finalize_received(k)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     fence()
-    pair_ms, fin_ms, pack_ms = [], [], []
+    pair_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        ms = eng.last_kernel_ms()     # HIP events recorded on the launch stream
-        pair_ms.append(ms["pair_ms"])
-        fin_ms.append(ms["finalize_ms"])
-        pack_ms.append(ms["pack_ms"])
+        pair_ms.append(eng.last_kernel_ms()["pair_ms"])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = total_pairs / (elapsed / args.steps)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    used = eng.last_path()
 
     if rank == 0:
-        # roofline of the dominant kernel (pair_kernel): algorithmic bytes per launch = pairs of
-        # the launch x (2L read + 8 written); duration = HIP events around the launch
         k_ms = float(np.mean(pair_ms))
-        # the HIP events bracket the LAST pair-kernel launch of a step: the whole range at N=1,
-        # the last sub-slab at N>1
-        launch_pairs = sub_offs[rank][chunks] - sub_offs[rank][chunks - 1]
-        algo_bytes = launch_pairs * (2 * L + 8)
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        words = (L + 127) // 128 * 4
-        traffic = measured_traffic(args.workload if not (args.n or args.len or args.measure) else "", args.variant)
-        lane_ops = launch_pairs * words * OPS_PER_WORD[measure] / (k_ms * 1e-3)
+        launch_pairs = sub_offs[rank][chunks] - sub_offs[rank][chunks - 1]   # the events bracket the LAST sub-slab launch
         result = {
             "metric": "pairwise comparisons/sec",
-            "value": value,
+            "value": total_pairs / (elapsed / args.steps),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order"
-                                   f"{', RCCL send/recv of slabs to rank 0' if world > 1 else ''})",
-                       "name": args.workload, "n": n, "len": L, "measure": measure,
-                       "pairs": total_pairs, "partition": f"{world} contiguous row ranges of equal pair count" + (f" (rank 0: {first_share:.4f} of the pairs, it also finalises the gathered tallies)" if first_share else "") + (f", {chunks} sub-slabs each, sends overlapped with compute, " + ("uint16 tallies" if wire16 else "f64") + " on the wire" if world > 1 else ""),
+            "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order, "
+                                   "RCCL send/recv of slabs to rank 0)",
+                       "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs, "path": used,
+                       "partition": f"{world} contiguous row ranges of equal pair count"
+                                    + (f" (rank 0: {first_share:.4f} of the pairs — it also finalises the gathered tallies; "
+                                       f"share sized from the measured {pair_rate:.3e} pairs/s per rank)" if first_share else "")
+                                    + f", {chunks} sub-slabs each, sends overlapped with compute, "
+                                    + ("uint16 tallies" if wire16 else "f64") + " on the wire",
+                       "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
+                       "note": "the gather of the N^2/2 results to ONE GPU is the job's exchange step; with the consensus "
+                               "path a single GPU finishes the compute faster than the results cross xGMI, so N>1 is "
+                               "bound by rank 0's ingest (DESIGN.md 6)",
                        "variant": args.variant},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic["hbm_bytes_per_launch"] if traffic and world == 1 else None),
-                         "traffic_source": (traffic["source"] if traffic and world == 1 else None),
-                         "kernel": "pair_kernel", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
-                         "note": "algorithmic bytes = pairs x (2L + 8); tiles reuse rows from LDS/registers, so "
-                                 "this exceeds physical HBM traffic (profiles/ has FETCH_SIZE); the true limiter "
-                                 "is VALU issue"},
-            "valu": {"achieved_lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                     "frac": lane_ops / VALU_PEAK_LANE_OPS, "ops_per_32_sites": OPS_PER_WORD[measure],
-                     "ns_per_32site_step_per_simd": k_ms * 1e6 / (launch_pairs * words / 65536.0),
-                     "measured_issue_ceiling_ns": RAW_STEP_CEILING_NS if measure in ("raw", "jc69") else None,
-                     "note": "v_bcnt_u32_b32 issues at half rate on gfx950, so the nominal full-rate peak is not "
-                             "reachable by this instruction mix; the ceiling is a pure-register microbenchmark "
-                             "of the same 7 instructions"},
-            "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms, "finalize": float(np.mean(fin_ms))},
-            "site_compares_per_s": value * L,
+            "roofline": roofline(measure, used, k_ms, launch_pairs),
+            "site_compares_per_s": total_pairs / (elapsed / args.steps) * L,
         }
-        if args.verify:
-            check = da.Engine(dev_index)
-            check.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
-            torch.cuda.synchronize()
-            bad = 0
-            probe = sorted(set([0, 1, n // 3, n // 2, n - 2] + [b for b in bounds[1:-1]] + [b - 1 for b in bounds[1:-1]]))
-            for row in [r for r in probe if 0 <= r < n - 1]:
-                want = check.run_square(measure, row, row + 1)
-                lo = da.square_row_start(n, row)
-                got = full_out[lo:lo + len(want)].cpu().numpy()
-                bad += int(not np.array_equal(got, want, equal_nan=True))
-            check.close()
-            result["verify"] = {"rows_checked": len(probe), "rows_bad": bad}
-            assert bad == 0, "multi-rank result differs from a single-engine run"
-        if world == 1 and not args.no_cpu_baseline:
-            rows = min(n, 8000)
-            host = codes[:rows].cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(host, measure)
-        if world == 1 and not args.no_extra:
-            extra = {}
-            for name, m2 in (("tn93", "tn93"), ("n_high", "n_high")):
-                if m2 == measure:
-                    continue
-                eng.run_square_device(m2, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                eng.run_square_device(m2, rb, re, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                extra[f"{name}_pairs_per_s"] = total_pairs / dt
-            result["extra_untimed_region"] = extra
+        probe_rows = sorted(set([0, 1, n // 3, n // 2, n - 2] + [b for b in bounds[1:-1]] + [b - 1 for b in bounds[1:-1]]))
+        result["verify"] = verify_rows(eng, codes, full_out, n, L, measure, probe_rows, dev_index, stream)
         print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
     eng.close()
+
+
+def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream) -> dict:
+    """Sampled rows of the job's result against a fresh single-engine run of just those rows (dense path)."""
+    check = da.Engine(dev_index)
+    check.set_path("dense")
+    check.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+    torch.cuda.synchronize()
+    bad = 0
+    rows = [r for r in rows if 0 <= r < n - 1]
+    for row in rows:
+        want = check.run_square(measure, row, row + 1)
+        lo = da.square_row_start(n, row)
+        got = full_out[lo:lo + len(want)].cpu().numpy()
+        bad += int(not np.array_equal(got, want, equal_nan=True))
+    check.close()
+    assert bad == 0, "the job's result differs from a single-engine dense run"
+    return {"rows_checked": len(rows), "rows_bad": bad, "against": "single-engine dense-path run of the same rows"}
 
 
 if __name__ == "__main__":

@@ -68,6 +68,12 @@ _SIGS = {
     "dst_run_rect_host": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp,
                                     C.c_size_t]),
     "dst_run_slabs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
+    "dst_stream_open": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "dst_stream_acquire": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
+    "dst_stream_submit": (C.c_int, [_vp, C.c_size_t, C.c_int]),
+    "dst_stream_collect": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(_vp)]),
+    "dst_stream_in_flight": (C.c_int, [_vp]),
+    "dst_stream_close": (C.c_int, [_vp]),
     "dst_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "dst_host_free": (C.c_int, [_vp]),
     "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),

@@ -9,52 +9,11 @@
 #include <new>
 #include <vector>
 
-#include "dst_internal.h"
+#include "dst_ctx.h"
 
 using namespace dst;
 
-struct dst_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    DeviceSet set[2];
-    // staging for host uploads / unaligned device inputs
-    uint8_t *stage = nullptr;
-    size_t stage_bytes = 0;
-    unsigned long long *d_first_bad = nullptr;
-    // tile schedules already on the device, keyed by the launch geometry (multi-GPU runs cycle
-    // through a few sub-slab ranges every step: no host sync or H2D on a hit)
-    struct Schedule {
-        bool square = false;
-        uint64_t rb = 0, re = 0, ncols = 0;
-        int bm = 0, bn = 0;  // dense tile shape; consensus-path tile lists: bm = rows per tile, bn = -1
-        uint32_t nblocks = 0;
-        void *d_blocks = nullptr;
-        uint64_t last_use = 0;
-    };
-    std::vector<Schedule> schedules;
-    uint64_t schedule_clock = 0;
-    int variant = 0;
-    int path = DST_PATH_AUTO;         // dst_set_path
-    int last_path = DST_PATH_DENSE;   // what the most recent run used
-    // consensus path: tables, counters and scratch shared by the two sets
-    ConsensusLut *d_lut = nullptr;
-    unsigned long long *d_total = nullptr;
-    uint32_t *scan_tmp = nullptr;
-    size_t scan_tmp_bytes = 0;
-    uint32_t *site_cur = nullptr;
-    size_t site_cur_bytes = 0;
-    int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
-    uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
-    size_t scratch_bytes = 0;
-    hipEvent_t scratch_free = nullptr;  // recorded after the last reader of `scratch`
-    bool scratch_used = false;
-    hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
-    float pair_ms = 0, pack_ms = 0;
-    bool timed_pair = false, timed_pack = false;
-    std::string err;
-};
-
-namespace {
+namespace dst {
 
 std::string g_create_err;
 std::mutex g_create_mu;
@@ -71,13 +30,6 @@ int fail_hip(dst_ctx *ctx, hipError_t e, const char *what)
     return fail(ctx, e == hipErrorOutOfMemory ? DST_ERR_NOMEM : DST_ERR_HIP,
                 std::string(what) + ": " + hipGetErrorString(e));
 }
-
-#define HIP_TRY(ctx, call)                       \
-    do {                                         \
-        hipError_t e_ = (call);                  \
-        if (e_ != hipSuccess)                    \
-            return fail_hip((ctx), e_, #call);   \
-    } while (0)
 
 int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 {
@@ -134,16 +86,17 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     return DST_OK;
 }
 
-int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, size_t len,
-                     size_t row_stride, const uint32_t *d_counts, hipStream_t stream)
+// queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the first
+// offending byte's index (or stays ~0).  Nothing here waits for the device.
+int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream)
 {
-    DeviceSet &s = ctx->set[slot];
     int rc = shape_set(ctx, s, n, len);
     if (rc)
         return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_bad, 0xFF, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, ctx->d_first_bad, stream));
+    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->timed_pack = true;
     if (d_counts) {
@@ -152,17 +105,31 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
                                     hipMemcpyDeviceToDevice, stream));
         s.have_counts = true;
     }
+    return DST_OK;
+}
+
+int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len)
+{
+    char msg[160];
+    std::snprintf(msg, sizeof msg,
+                  "invalid nucleotide code in record %llu at site %llu (not a value src/encoding.rs produces)",
+                  first_bad / (len ? len : 1), first_bad % (len ? len : 1));
+    return fail(ctx, DST_ERR_INVALID_CODE, msg);
+}
+
+int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, size_t len,
+                     size_t row_stride, const uint32_t *d_counts, hipStream_t stream)
+{
+    DeviceSet &s = ctx->set[slot];
+    int rc = pack_queue(ctx, s, d_codes, n, len, row_stride, d_counts, ctx->d_first_bad, stream);
+    if (rc)
+        return rc;
     unsigned long long first_bad = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof first_bad, hipMemcpyDeviceToHost,
                                 stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    if (first_bad != ~0ull) {
-        char msg[160];
-        std::snprintf(msg, sizeof msg,
-                      "invalid nucleotide code in record %llu at site %llu (not a value src/encoding.rs produces)",
-                      first_bad / (len ? len : 1), first_bad % (len ? len : 1));
-        return fail(ctx, DST_ERR_INVALID_CODE, msg);
-    }
+    if (first_bad != ~0ull)
+        return invalid_code_error(ctx, first_bad, len);
     s.loaded = true;
     return DST_OK;
 }
@@ -405,14 +372,19 @@ int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slo
 {
     if (!ctx)
         return DST_ERR_ARG;
+    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
+        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
+    return run_sets(ctx, measure, square, ctx->set[row_slot], ctx->set[col_slot], rb, re, out_kind, d_out, cap, stream_v);
+}
+
+// rows [rb, re) of `rows` against every (square: later) record of `cols` — any two packed sets of this context
+int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet &cols, uint64_t rb, uint64_t re,
+             int out_kind, void *d_out, size_t cap, void *stream_v)
+{
     if (measure < DST_N || measure > DST_TN93)
         return fail(ctx, DST_ERR_ARG, "unknown measure");
     if (out_kind != DST_OUT_DISTANCE && out_kind != DST_OUT_TALLY && out_kind != DST_OUT_TALLY16)
         return fail(ctx, DST_ERR_ARG, "unknown output kind");
-    if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
-        return fail(ctx, DST_ERR_ARG, "slot must be 0 or 1");
-    DeviceSet &rows = ctx->set[row_slot];
-    DeviceSet &cols = ctx->set[col_slot];
     if (!rows.loaded || !cols.loaded)
         return fail(ctx, DST_ERR_STATE, "set not uploaded");
     if (rows.len != cols.len) {
@@ -607,7 +579,7 @@ int run_host(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot,
     return rc;
 }
 
-}  // namespace
+}  // namespace dst
 
 extern "C" {
 

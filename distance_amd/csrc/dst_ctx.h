@@ -1,0 +1,75 @@
+// dst_ctx.h — the context behind the C ABI and the helpers its translation units share
+// (dst_api.cpp: uploads and runs, dst_stream.cpp: the stream-mode pipeline, dst_gather.cpp: multi-GPU gather).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "dst_internal.h"
+
+using namespace dst;
+
+struct dst_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceSet set[2];
+    // staging for host uploads / unaligned device inputs
+    uint8_t *stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned long long *d_first_bad = nullptr;
+    // tile schedules already on the device, keyed by the launch geometry (multi-GPU runs cycle
+    // through a few sub-slab ranges every step: no host sync or H2D on a hit)
+    struct Schedule {
+        bool square = false;
+        uint64_t rb = 0, re = 0, ncols = 0;
+        int bm = 0, bn = 0;  // dense tile shape; consensus-path tile lists: bm = rows per tile, bn = -1
+        uint32_t nblocks = 0;
+        void *d_blocks = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::vector<Schedule> schedules;
+    uint64_t schedule_clock = 0;
+    int variant = 0;
+    int path = DST_PATH_AUTO;         // dst_set_path
+    int last_path = DST_PATH_DENSE;   // what the most recent run used
+    // consensus path: tables, counters and scratch shared by the two sets
+    ConsensusLut *d_lut = nullptr;
+    unsigned long long *d_total = nullptr;
+    uint32_t *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    uint32_t *site_cur = nullptr;
+    size_t site_cur_bytes = 0;
+    int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
+    uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
+    size_t scratch_bytes = 0;
+    hipEvent_t scratch_free = nullptr;  // recorded after the last reader of `scratch`
+    bool scratch_used = false;
+    hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
+    float pair_ms = 0, pack_ms = 0;
+    bool timed_pair = false, timed_pack = false;
+    std::string err;
+};
+
+namespace dst {
+
+int fail(dst_ctx *ctx, int status, const std::string &msg);
+int fail_hip(dst_ctx *ctx, hipError_t e, const char *what);
+
+#define HIP_TRY(ctx, call)                       \
+    do {                                         \
+        hipError_t e_ = (call);                  \
+        if (e_ != hipSuccess)                    \
+            return dst::fail_hip((ctx), e_, #call); \
+    } while (0)
+
+int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want);
+void free_set(DeviceSet &s);
+// queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the index of the first
+// byte that is not a Paradis code (or stays ~0).  Nothing here waits for the device.
+int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream);
+int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len);
+// rows [rb, re) of `rows` against every (square: later) record of `cols` — any two packed sets of this context
+int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet &cols, uint64_t rb, uint64_t re,
+             int out_kind, void *d_out, size_t cap, void *stream_v);
+
+}  // namespace dst

@@ -246,6 +246,10 @@ class Engine:
         self.upload(1, batch_codes, batch_counts)
         return self.run_rect(measure, row_slot=1, col_slot=0, tallies=tallies)
 
+    def stream(self, measure, max_records: int, depth: int = 3, tallies: bool = False) -> "Stream":
+        """The overlapped stream-mode pipeline (dst_stream_*): batches against the loaded set of slot 0."""
+        return Stream(self, measure, max_records, depth, tallies)
+
     def run_slabs(self, measure, sink, max_pairs: int, square: bool = True, row_slot: int = 0, col_slot: int = 1,
                   tallies: bool = False):
         """In-order slab sink (dst_run_slabs): sink(first_pair, rb, re, array) per slab; a truthy return stops."""
@@ -294,3 +298,63 @@ class Engine:
     def out_bytes(self, measure, pairs: int, tallies: bool = False) -> int:
         return int(self._lib.dst_out_bytes(_measure_id(measure), OUT_TALLY if tallies else OUT_DISTANCE,
                                            pairs))
+
+
+class Stream:
+    """dst_stream_*: stream()'s batches (src/lib.rs:269-365) through page-locked ring slots, H2D / compare / D2H
+    overlapped.  push() copies a batch into the acquired buffer and submits it; pop() returns the oldest batch's
+    results [streamed record][loaded record] (a copy)."""
+
+    def __init__(self, eng: Engine, measure, max_records: int, depth: int, tallies: bool):
+        self._eng, self._lib = eng, eng._lib
+        self._m = _measure_id(measure)
+        self._kind = OUT_TALLY if tallies else OUT_DISTANCE
+        self._n_loaded, self._len = eng.set_info(0)
+        self.max_records, self.depth = max_records, depth
+        h = C.c_void_p()
+        eng._check(self._lib.dst_stream_open(eng._h, self._m, self._kind, max_records, depth, C.byref(h)))
+        self._h = h
+
+    def buffer(self):
+        """(codes view (max_records, width) into the page-locked input buffer, counts view (max_records, 4))"""
+        p, pitch, cnt = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        self._eng._check(self._lib.dst_stream_acquire(self._h, C.byref(p), C.byref(pitch), C.byref(cnt)))
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.max_records, pitch.value))
+        counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_uint32)), shape=(self.max_records, 4))
+        return raw[:, :self._len], counts
+
+    def submit(self, n_records: int, use_counts: bool = False):
+        self._eng._check(self._lib.dst_stream_submit(self._h, n_records, int(use_counts)))
+
+    def push(self, codes: np.ndarray, counts=None):
+        buf, cbuf = self.buffer()
+        buf[:len(codes)] = codes
+        if counts is not None:
+            cbuf[:len(codes)] = counts
+        self.submit(len(codes), counts is not None)
+
+    def in_flight(self) -> int:
+        return int(self._lib.dst_stream_in_flight(self._h))
+
+    def pop(self, copy: bool = True) -> np.ndarray:
+        n, p = C.c_size_t(), C.c_void_p()
+        self._eng._check(self._lib.dst_stream_collect(self._h, C.byref(n), C.byref(p)))
+        if self._kind == OUT_TALLY:
+            w = self._lib.dst_tally_width(self._m)
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, self._n_loaded, w))
+        elif self._m in (0, 1):
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(n.value, self._n_loaded))
+        else:
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(n.value, self._n_loaded))
+        return arr.copy() if copy else arr
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dst_stream_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

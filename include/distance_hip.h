@@ -169,6 +169,30 @@ int dst_run_square_host(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t 
                         int out_kind, void *h_out, size_t out_capacity_bytes);
 int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin,
                       uint64_t row_end, int out_kind, void *h_out, size_t out_capacity_bytes);
+/* ---- stream mode: replaces stream()'s worker pool (src/lib.rs:269-365) ----------------------- */
+/* Batches of streamed records (rows) against the loaded set of slot 0 (columns), results in the reference's
+ * streamed-major order [streamed record][loaded record] (src/lib.rs:322-331), through a ring of `depth` slots
+ * (2..16) on three HIP streams: while batch k is compared, batch k+1 crosses PCIe from page-locked memory and
+ * batch k-1's results travel back.  out_kind: DST_OUT_DISTANCE or DST_OUT_TALLY.  max_records: records per batch
+ * (stream_fasta()'s batchsize, src/fastaio.rs:215-286).  The width is slot 0's; slot 0 must stay loaded and
+ * unchanged while the stream is open.  One owner thread, like the context. */
+typedef struct dst_stream dst_stream;
+int dst_stream_open(dst_ctx *ctx, int measure, int out_kind, size_t max_records, int depth, dst_stream **stream);
+/* The page-locked input buffer of the next batch: rows *pitch bytes apart (>= width, a multiple of 128), room
+ * for max_records; encode straight into it.  *base_counts (may be NULL): max_records x 4 {A,T,G,C} for tn93
+ * (encode_count_bases(), src/fastaio.rs:120-145).  DST_ERR_STATE when every slot is in flight. */
+int dst_stream_acquire(dst_stream *stream, uint8_t **codes, size_t *pitch, uint32_t **base_counts);
+/* Queue the acquired buffer holding n_records records: H2D, pack, compare, D2H.  Returns without waiting.
+ * use_base_counts != 0: tn93 uses the caller's counts (streamed records: upper-case letters only,
+ * src/fastaio.rs:136-142), else they are counted on the device by code. */
+int dst_stream_submit(dst_stream *stream, size_t n_records, int use_base_counts);
+/* Wait for the OLDEST submitted batch and hand out its results (page-locked, library-owned, valid until the next
+ * dst_stream_submit): n_records x (records of slot 0) x the per-pair payload of out_kind.
+ * DST_ERR_INVALID_CODE when the batch held a byte src/encoding.rs never produces. */
+int dst_stream_collect(dst_stream *stream, size_t *n_records, const void **results);
+int dst_stream_in_flight(const dst_stream *stream);   /* submitted, not yet collected */
+int dst_stream_close(dst_stream *stream);
+
 /* In-order sink (the shape of gather_write's input, src/lib.rs:612-644): the run is cut into row
  * slabs of at most max_pairs pairs (>= one row each) and `sink` is called once per slab, strictly
  * in canonical order, on the calling thread, with the slab's results in library-owned pinned host

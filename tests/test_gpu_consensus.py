@@ -176,14 +176,18 @@ def test_rectangle_and_stream_against_another_sets_reference(eng):
 
 
 def test_auto_picks_by_diversity(eng):
+    from tools import synth
     eng.set_path("auto")
-    low = low_diversity(3000, 6000, 11)
+    low = synth.alignment(7, 12000, 6000)             # SURVEY 8(d)'s diversity: ~13 differing sites per record
     eng.upload(0, low)
     d_low = eng.run_square("raw")
     assert eng.last_path() == "consensus"
     high = uniform_codes(3000, 6000, 12)              # every code equally likely: nothing to gain from lists
     eng.upload(0, high)
     eng.run_square("raw", 0, 64)
+    assert eng.last_path() == "dense"
+    eng.upload(0, low[:40])                           # a launch too small to pay for building the lists
+    eng.run_square("raw")
     assert eng.last_path() == "dense"
     eng.upload(0, low)
     eng.set_path("dense")
