@@ -47,8 +47,8 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.nib, s.ref.planes, s.ref.stats, s.rec.off, s.rec.ent,
-                    s.site.off, s.site.ent, s.aconst};
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.stats, s.rec.off, s.rec.ent,
+                    s.site.cnt, s.site.off, s.site.tab, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -219,12 +219,12 @@ int prepare_blocks(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64_t
 // consensus-delta path: reference, difference lists, path choice (kernels: dst_consensus.hip)
 // =============================================================================================
 constexpr uint64_t kMaxListEntries = 0x7FFFFFFFull;  // 32-bit CSR offsets
-constexpr uint32_t kConsensusRowsPerTile = 8;
+constexpr uint32_t kConsensusRowsPerTile = kTileRowsMax;
 
 bool consensus_shape_ok(const DeviceSet &rows, const DeviceSet &cols)
 {
     // list entries carry a site or a record in 28 bits next to the nibble
-    return rows.n < kEntryMask && cols.n < kEntryMask && rows.len < kEntryMask && rows.len == cols.len && rows.len > 0;
+    return rows.n < kEntryMask && cols.n < kEntryMask && rows.len < kSiteMask && rows.len == cols.len && rows.len > 0;
 }
 
 int ensure_lut(dst_ctx *ctx)
@@ -244,14 +244,12 @@ int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
     if (s.ref.valid)
         return DST_OK;
-    if (s.ref.nchunks != s.nchunks || !s.ref.nib) {
-        for (void *b : {(void *)s.ref.nib, (void *)s.ref.planes, (void *)s.ref.stats})
+    if (s.ref.nchunks != s.nchunks || !s.ref.planes) {
+        for (void *b : {(void *)s.ref.planes, (void *)s.ref.stats})
             if (b)
                 HIP_TRY(ctx, hipFree(b));
-        s.ref.nib = nullptr;
         s.ref.planes = nullptr;
         s.ref.stats = nullptr;
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.nib, s.nchunks * kChunkSites));
         HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
         HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 4 * sizeof(uint64_t)));
         s.ref.nchunks = s.nchunks;
@@ -277,7 +275,11 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     const size_t n_buckets = want_sites ? s.nchunks * kChunkSites * (size_t)n_panels : 0;
     int rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.cnt, &s.site.cnt_cap, (n_buckets + 1) * sizeof(uint32_t));
+    if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.off, &s.site.off_cap, (n_buckets + 1) * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.tab, &s.site.tab_cap, std::max<size_t>(n_buckets, 1) * sizeof(uint2));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&ctx->site_cur, &ctx->site_cur_bytes, (n_buckets + 1) * sizeof(uint32_t));
     if (!rc)
@@ -289,24 +291,28 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     s.site.valid = false;
     HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
     if (want_sites)
-        HIP_TRY(ctx, hipMemsetAsync(s.site.off, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.site.cnt, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, false, want_sites, false, s.rec.off, nullptr, s.site.off, nullptr,
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, false, want_sites, false, s.rec.off, nullptr, s.site.cnt, nullptr,
                               nullptr, n_panels, ctx->d_total, stream));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    if (total > kMaxListEntries)
+    if (total > kMaxListEntries / 4)
         return fail(ctx, DST_ERR_CAPACITY, "too many differences from the reference sequence for the consensus path");
     s.rec.total = total;
+    // buckets start on 16-byte boundaries: at most 3 entries of padding per non-empty bucket
+    const size_t padded_cap = (size_t)total + 3 * std::min<size_t>(total, n_buckets) + 4;
     rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, std::max<size_t>(total, 1) * sizeof(uint32_t));
     if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, std::max<size_t>(total, 1) * sizeof(uint32_t));
+        rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, padded_cap * sizeof(uint32_t));
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
     if (want_sites) {
+        HIP_TRY(ctx, launch_pad_counts(s.site.cnt, s.site.off, n_buckets, stream));
         HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
+        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->site_cur, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
     }
     HIP_TRY(ctx, launch_index(s, refset.ref.planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
@@ -334,7 +340,7 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
     int rc = ensure_bytes(ctx, (void **)&s.aconst, &s.aconst_cap, s.npad * kMaxWords * sizeof(uint32_t));
     if (rc)
         return rc;
-    HIP_TRY(ctx, launch_aconst(s, refset.ref.nib, family, wide, ctx->d_lut, stream));
+    HIP_TRY(ctx, launch_aconst(s, family, wide, ctx->d_lut, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     s.aconst_family = family;
     s.aconst_wide = wide;
@@ -913,7 +919,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e != hipSuccess)
         return done(fail_hip(ctx, e, "differences (fill)"));
     for (uint64_t k = 0; k < total; ++k)
-        sites[k] &= kEntryMask;  // drop the nibble the pair kernel's lists carry
+        sites[k] &= kSiteMask;  // drop the reference class and the nibble the pair kernel's lists carry
     return done(DST_OK);
 }
 

@@ -16,10 +16,10 @@
 //
 //   ref_sample_kernel   per-site plurality code over a sample of records -> the reference c
 //   index_kernel        per record: ascending list of (site, nibble) where it differs from c; and the
-//                       same entries bucketed by (site, panel of 8,192 column records)
+//                       same entries bucketed by (site, panel of 2,048 column records)
 //   scan kernels        exclusive scan of the list lengths -> CSR offsets
 //   aconst_kernel       A_k(record), packed like the accumulators
-//   consensus_pair_kernel  one block = a few rows x one column panel: the row's list is joined with the
+//   consensus_pair_kernel  one block = a few rows x one column panel: the rows' lists are joined with the
 //                       site buckets of the panel, h_k goes into LDS accumulators (ds_add_u32), then one
 //                       coalesced pass adds the per-record constants, finalises (f64, reference operation
 //                       order) and stores in canonical order
@@ -51,8 +51,7 @@ __device__ __forceinline__ uint32_t popc4(uint4 v)
 // work the pair kernel has.
 __global__ __launch_bounds__(128) void ref_sample_kernel(const uint32_t *__restrict__ planes32, uint32_t n,
                                                          uint32_t len, uint32_t nchunks, uint32_t npad,
-                                                         uint32_t samples, uint8_t *__restrict__ ref_nib,
-                                                         uint4 *__restrict__ ref_planes,
+                                                         uint32_t samples, uint4 *__restrict__ ref_planes,
                                                          unsigned long long *__restrict__ stats)
 {
     const uint32_t c = blockIdx.x, b = threadIdx.x;
@@ -81,7 +80,6 @@ __global__ __launch_bounds__(128) void ref_sample_kernel(const uint32_t *__restr
     const uint32_t site = c * kChunkSites + b;
     const bool real = site < len;
     const uint32_t nib = !real ? 15u : cls == 0 ? 8u : cls == 1 ? 4u : cls == 2 ? 2u : cls == 3 ? 1u : 15u;
-    ref_nib[site] = (uint8_t)nib;
     const uint32_t wave = b >> 6;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -135,15 +133,17 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
     const uint32_t base0 = (FILL && live) ? rec[r] : 0u;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
         const uint32_t c = c0 + cl;
-        uint4 A = make_uint4(0, 0, 0, 0), G = A, C = A, T = A, d = A;
+        uint4 A = make_uint4(0, 0, 0, 0), G = A, C = A, T = A, d = A, rA = A, rG = A, rC = A, rT = A;
         if (live && c < nchunks) {
             const size_t at = (size_t)c * npad + r;
             A = planes[PL_A * ps + at];
             G = planes[PL_G * ps + at];
             C = planes[PL_C * ps + at];
             T = planes[PL_T * ps + at];
-            const uint4 rA = ref_planes[c], rG = ref_planes[nchunks + c];
-            const uint4 rC = ref_planes[2 * (size_t)nchunks + c], rT = ref_planes[3 * (size_t)nchunks + c];
+            rA = ref_planes[c];
+            rG = ref_planes[nchunks + c];
+            rC = ref_planes[2 * (size_t)nchunks + c];
+            rT = ref_planes[3 * (size_t)nchunks + c];
             d.x = (A.x ^ rA.x) | (G.x ^ rG.x) | (C.x ^ rC.x) | (T.x ^ rT.x);
             d.y = (A.y ^ rA.y) | (G.y ^ rG.y) | (C.y ^ rC.y) | (T.y ^ rT.y);
             d.z = (A.z ^ rA.z) | (G.z ^ rG.z) | (C.z ^ rC.z) | (T.z ^ rT.z);
@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
             const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
             const uint32_t aw[4] = {A.x, A.y, A.z, A.w}, gw[4] = {G.x, G.y, G.z, G.w};
             const uint32_t cw[4] = {C.x, C.y, C.z, C.w}, tw[4] = {T.x, T.y, T.z, T.w};
+            const uint32_t raw[4] = {rA.x, rA.y, rA.z, rA.w}, rgw[4] = {rG.x, rG.y, rG.z, rG.w};
+            const uint32_t rcw[4] = {rC.x, rC.y, rC.z, rC.w}, rtw[4] = {rT.x, rT.y, rT.z, rT.w};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 uint32_t m = dw[w];
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                     if constexpr (FILL) {
                         const uint32_t nib = ((aw[w] >> bit) & 1u) << 3 | ((gw[w] >> bit) & 1u) << 2 |
                                              ((cw[w] >> bit) & 1u) << 1 | ((tw[w] >> bit) & 1u);
-                        rec_ent[at++] = s | nib << kEntryShift;
+                        const uint32_t rnib = ((raw[w] >> bit) & 1u) << 3 | ((rgw[w] >> bit) & 1u) << 2 |
+                                              ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
+                        rec_ent[at++] = s | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
                         if (want_sites) {
                             const size_t bk = (size_t)s * n_panels + panel;
                             const uint32_t pos = atomicAdd(&site_cur[bk], 1u);
@@ -256,12 +260,29 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
             data[base + k] += off;
 }
 
+__global__ __launch_bounds__(256) void pad_counts_kernel(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ padded,
+                                                          size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        padded[i] = (cnt[i] + 3u) & ~3u;
+    else if (i == n)
+        padded[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void site_table_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt,
+                                                          uint2 *__restrict__ tab, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        tab[i] = make_uint2(off[i], cnt[i]);
+}
+
 // =============================================================================================
 // per-record constants A_k
 // =============================================================================================
 __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict__ off,
                                                      const uint32_t *__restrict__ ent,
-                                                     const uint8_t *__restrict__ ref_nib,
                                                      const ConsensusLut *__restrict__ lut, int family, int wide,
                                                      int words, uint32_t n, uint32_t npad,
                                                      uint32_t *__restrict__ aconst)
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict_
     uint32_t acc[kMaxWords] = {0, 0, 0, 0};
     for (uint32_t i = off[r] + lane; i < off[r + 1]; i += 64) {
         const uint32_t e = ent[i];
-        const uint32_t *a = lut->a[family][wide][ref_class(ref_nib[e & kEntryMask])][e >> kEntryShift];
+        const uint32_t *a = lut->a[family][wide][(e >> kSiteBits) & 7u][e >> kEntryShift];
 #pragma unroll
         for (int w = 0; w < kMaxWords; ++w)
             acc[w] += a[w];
@@ -317,150 +338,288 @@ struct FWords {
     uint32_t w[kMaxWords];
 };
 
-// One block = rows [i0, i1) x one panel of up to kPanelCols column records, 256 threads.
-// Per row:  A) each thread takes one entry (site, nibble) of the row's list and looks up the panel's
-//              bucket of that site; a block-wide exclusive scan of the bucket sizes numbers the candidate
-//              events;
-//           B) the events are dealt to the threads (binary search in the scanned sizes): column record
-//              and nibble from the bucket, h_k from the table, ds_add_u32 into the column's accumulators;
-//           C) every thread walks its columns (coalesced): accumulator + A(column) + A(row) + F, unpack,
-//              finalise, store in canonical order; touched accumulators are reset on the way.
-// A row's list longer than 256 entries repeats A/B in slices.
+struct __attribute__((packed, aligned(8))) F64x2 {  // two adjacent results, 8-byte aligned: one 16-byte store
+    double a, b;
+};
+struct __attribute__((packed, aligned(8))) I64x2 {
+    int64_t a, b;
+};
+
+// One block = rows [i0, i1) x one panel of up to kPanelCols column records; the rows go through kAccRows at a
+// time (a "batch"; their lists are adjacent in the CSR, so a batch is one run of entries).  512 threads in two
+// roles that work on consecutive batches at the same time, with the accumulators double-buffered in LDS:
+//   event waves (4): A) lane k takes entry k of the batch's lists: (site, reference class, nibble) -> the
+//      panel's bucket of that site from the lookup table (one 8-byte load) -> the bucket's first INL column
+//      entries (16-byte loads; buckets start on 16-byte boundaries);  B) every candidate event (column record,
+//      nibble) gets h_k from the table in LDS and goes into the (row, column) accumulators with ds_add_u32.
+//      Buckets larger than INL are shared out over the wave (scan of the sizes + search by shuffles);
+//      batches with more than 256 entries run extra slices.  No barrier inside A/B.
+//   output waves (4): C) every thread walks its column PAIRS (16-byte stores) for each row of the PREVIOUS
+//      batch: accumulator + A(column) + A(row) + F, unpack, finalise, store in canonical order; touched
+//      accumulators are reset on the way.  A(column) stays in registers for the whole tile.
+// One barrier per batch.  Why two roles: gfx950 counts loads and stores in ONE in-order counter (vmcnt), so a
+// wave that has just issued its result stores cannot consume a younger load before those stores have
+// landed in HBM; the event waves' chains of dependent random loads never queue behind a store this way.
 template <int FAM, bool WIDE, int OUT>
-__global__ __launch_bounds__(256) void consensus_pair_kernel(
+__global__ __launch_bounds__(512) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
-    const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint32_t *__restrict__ site_off,
+    const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint2 *__restrict__ site_tab,
     const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
-    uint32_t n_panels, const uint8_t *__restrict__ ref_nib, const ConsensusLut *__restrict__ lut, FWords fw,
+    uint32_t n_panels, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
     const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square)
 {
     using P = Pack<FAM, WIDE>;
     constexpr int W = P::W, NT = P::NT;
+    constexpr int RB = kAccRows;
+    constexpr int PAIRS = kPanelCols / 512;      // column pairs per output thread
+    constexpr int INL = 8;                        // events a lane applies for its own entry before the wave shares the rest
+    constexpr uint32_t ACC = RB * W * kPanelCols;  // words of one accumulator buffer
     extern __shared__ uint32_t smem[];
-    uint32_t *acc = smem;                        // [W][kPanelCols]
-    uint32_t *seg_start = smem + W * kPanelCols;  // [257] scanned bucket sizes of the current slice
-    uint32_t *seg_o0 = seg_start + 257;          // [256] bucket start in site_ent
-    uint32_t *seg_meta = seg_o0 + 256;           // [256] reference class * 16 + row nibble
-    uint32_t *wave_tot = seg_meta + 256;         // [4]
+    uint32_t *acc = smem;                                  // [2][RB][W][kPanelCols]
+    uint32_t *hlut = smem + 2 * ACC;                       // [kRefClasses][16][16][W]: h_k of this family
+    uint32_t *rofs = hlut + kRefClasses * 256 * W;         // [kTileRowsMax + 1] list offsets of the tile's rows
 
     const ConsensusTile tile = tiles[blockIdx.x];
     const uint32_t panel0 = tile.panel * kPanelCols;
     const uint32_t pcols = min(kPanelCols, n_cols - panel0);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t k = tid; k < W * kPanelCols; k += 256)
+    const bool event_role = threadIdx.x >= 256;
+    const uint32_t tid = threadIdx.x & 255u, lane = tid & 63u;
+    const uint32_t trows = tile.i1 - tile.i0;              // <= kTileRowsMax
+    const uint32_t nbatch = (trows + RB - 1) / RB;
+    for (uint32_t k = threadIdx.x; k < 2 * ACC; k += 512)
         acc[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kRefClasses * 256 * W; k += 512)
+        hlut[k] = (&lut->h[FAM][WIDE ? 1 : 0][0][0][0][0])[(k / W) * kMaxWords + k % W];
+    if (threadIdx.x <= trows)
+        rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
+    // A(column) of an output thread's column pairs: constant over the rows of the tile
+    uint32_t ca[PAIRS][2][W];
+#pragma unroll
+    for (int j = 0; j < PAIRS; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t k = 2 * tid + 512 * j + h;
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+        }
     __syncthreads();
 
-    for (uint32_t q = tile.i0; q < tile.i1; ++q) {
-        const uint32_t e0 = row_off[q], e1 = row_off[q + 1];
-        for (uint32_t eb = e0; eb < e1; eb += 256) {
-            // ---- A: bucket of every entry of the slice, scanned
-            uint32_t cnt = 0, o0 = 0, meta = 0;
-            if (eb + tid < e1) {
-                const uint32_t e = row_ent[eb + tid];
-                const uint32_t s = e & kEntryMask;
-                const size_t bk = (size_t)s * n_panels + tile.panel;
-                o0 = site_off[bk];
-                cnt = site_off[bk + 1] - o0;
-                meta = (uint32_t)ref_class(ref_nib[s]) * 16u + (e >> kEntryShift);
+    // ---- event waves: the three stages of A, pipelined in registers across batches (entry of batch b+3,
+    // bucket of batch b+2, bucket entries of batch b+1 are in flight while batch b's events are applied)
+    struct Entry {   // stage 1: this lane's entry of a batch
+        uint32_t e, rb;
+        bool valid;
+    };
+    struct Bucket {  // stage 2: its bucket in this panel
+        uint32_t o0, cnt, meta;
+    };
+    auto load_entry = [&](uint32_t b, uint32_t first) {   // entry `first + tid` of batch b's run
+        Entry en{0u, 0u, false};
+        if (b < nbatch) {
+            const uint32_t r0 = b * RB;
+            const uint32_t ei = rofs[r0] + first + tid;
+            if (ei < rofs[min(r0 + RB, trows)]) {
+                en.valid = true;
+                en.e = row_ent[ei];
+#pragma unroll
+                for (int r = 1; r < RB; ++r)
+                    en.rb += ei >= rofs[min(r0 + r, trows)];
             }
-            uint32_t incl = cnt, up;
+        }
+        return en;
+    };
+    auto load_bucket = [&](const Entry &en) {
+        Bucket bk{0u, 0u, 0u};
+        if (en.valid) {
+            const uint2 tab = site_tab[(size_t)(en.e & kSiteMask) * n_panels + tile.panel];
+            bk.o0 = tab.x;
+            bk.cnt = tab.y;
+            bk.meta = en.rb << 8 | ((en.e >> kSiteBits) & 7u) << 4 | (en.e >> kEntryShift);
+        }
+        return bk;
+    };
+    auto load_events = [&](const Bucket &bk, uint4 *ce) {
+#pragma unroll
+        for (int j = 0; j < INL / 4; ++j)
+            ce[j] = (uint32_t)(4 * j) < bk.cnt ? reinterpret_cast<const uint4 *>(site_ent + bk.o0)[j] : make_uint4(0, 0, 0, 0);
+    };
+    // B for one lane's bucket of batch b: the first INL events from registers, the rest shared out over the wave
+    auto apply_bucket = [&](const Bucket &bk, const uint4 *ce, uint32_t b) {
+        const uint32_t q0 = tile.i0 + b * RB;
+        uint32_t *bacc = acc + (b & 1u) * ACC;
+        // one candidate event: column record + nibble from the bucket, h_k from the table, into the accumulators
+        auto apply = [&](uint32_t c, uint32_t meta) {
+            const uint32_t t = c & kEntryMask, rb = meta >> 8;
+            if (!square || t > q0 + rb) {
+                const uint32_t *h = hlut + (((meta & 255u) << 4) | (c >> kEntryShift)) * W;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint32_t v = h[w];
+                    if (v)
+                        atomicAdd(&bacc[(rb * W + w) * kPanelCols + (t - panel0)], v);
+                }
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < INL / 4; ++j) {
+            if ((uint32_t)(4 * j + 0) < bk.cnt) apply(ce[j].x, bk.meta);
+            if ((uint32_t)(4 * j + 1) < bk.cnt) apply(ce[j].y, bk.meta);
+            if ((uint32_t)(4 * j + 2) < bk.cnt) apply(ce[j].z, bk.meta);
+            if ((uint32_t)(4 * j + 3) < bk.cnt) apply(ce[j].w, bk.meta);
+        }
+        const uint32_t ex = bk.cnt > INL ? bk.cnt - INL : 0u;
+        if (__ballot(ex != 0)) {
+            uint32_t incl = ex, up;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 up = __shfl_up(incl, o);
                 if (lane >= (uint32_t)o) incl += up;
             }
-            if (lane == 63)
-                wave_tot[wave] = incl;
-            __syncthreads();
-            uint32_t woff = 0, total = 0;
+            const uint32_t total = __shfl(incl, 63), start = incl - ex;
+            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint32_t lo = 0;
 #pragma unroll
-            for (uint32_t wv = 0; wv < 4; ++wv) {
-                const uint32_t t = wave_tot[wv];
-                if (wv < wave) woff += t;
-                total += t;
-            }
-            seg_start[tid] = woff + incl - cnt;
-            seg_o0[tid] = o0;
-            seg_meta[tid] = meta;
-            if (tid == 0)
-                seg_start[256] = total;
-            __syncthreads();
-            // ---- B: one candidate event per thread per round
-            for (uint32_t i = tid; i < total; i += 256) {
-                uint32_t lo = 0, hi = 256;
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (seg_start[mid] <= i) lo = mid; else hi = mid;
+                for (int st = 32; st > 0; st >>= 1) {
+                    const uint32_t v = __shfl(start, (int)(lo + st));
+                    if (v <= i) lo += st;   // the last lane whose range starts at or before i (sizes may be 0)
                 }
-                const uint32_t ce = site_ent[seg_o0[lo] + (i - seg_start[lo])];
-                const uint32_t t = ce & kEntryMask;
-                if (!square || t > q) {
-                    const uint32_t m = seg_meta[lo];
-                    const uint32_t *h = lut->h[FAM][WIDE ? 1 : 0][m >> 4][m & 15u][ce >> kEntryShift];
+                const uint32_t s_o0 = __shfl(bk.o0, (int)lo), s_meta = __shfl(bk.meta, (int)lo), s_start = __shfl(start, (int)lo);
+                if (i < total)
+                    apply(site_ent[s_o0 + INL + (i - s_start)], s_meta);
+            }
+        }
+    };
+    Entry en_n3{0u, 0u, false};
+    Bucket bk_cur{0u, 0u, 0u}, bk_nx{0u, 0u, 0u}, bk_n2{0u, 0u, 0u};
+    uint4 ce_cur[INL / 4], ce_nx[INL / 4];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        const uint32_t v = h[w];
-                        if (v)
-                            atomicAdd(&acc[w * kPanelCols + (t - panel0)], v);
+    for (int j = 0; j < INL / 4; ++j)
+        ce_cur[j] = ce_nx[j] = make_uint4(0, 0, 0, 0);
+    if (event_role) {  // prologue: batch 0 fully staged, batch 1's bucket entries, batch 2's bucket, batch 3's entry
+        bk_cur = load_bucket(load_entry(0, 0));
+        load_events(bk_cur, ce_cur);
+        bk_nx = load_bucket(load_entry(1, 0));
+        load_events(bk_nx, ce_nx);
+        bk_n2 = load_bucket(load_entry(2, 0));
+        en_n3 = load_entry(3, 0);
+    }
+
+    for (uint32_t step = 0; step <= nbatch; ++step) {
+        if (event_role) {
+            if (step < nbatch) {
+                // ---- B of batch `step` into buffer step & 1
+                apply_bucket(bk_cur, ce_cur, step);
+                // entries beyond the 256 the pipeline carries (long lists): plain slices
+                const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
+                for (uint32_t first = 256; first < run; first += 256) {
+                    const Bucket bk = load_bucket(load_entry(step, first));
+                    uint4 ce[INL / 4];
+                    load_events(bk, ce);
+                    apply_bucket(bk, ce, step);
+                }
+                // rotate the pipeline and issue the next loads (consumed one step later each)
+                bk_cur = bk_nx;
+#pragma unroll
+                for (int j = 0; j < INL / 4; ++j)
+                    ce_cur[j] = ce_nx[j];
+                bk_nx = bk_n2;
+                load_events(bk_nx, ce_nx);
+                bk_n2 = load_bucket(en_n3);
+                en_n3 = load_entry(step + 4, 0);
+            }
+        } else if (step >= 1) {
+            // ---- C of batch step - 1 from buffer (step - 1) & 1: constants, finalisation, canonical-order store
+            const uint32_t b = step - 1, q0 = tile.i0 + b * RB;
+            const uint32_t nrows = min((uint32_t)RB, tile.i1 - q0);
+            for (uint32_t rb = 0; rb < nrows; ++rb) {
+                const uint32_t q = q0 + rb;
+                uint32_t aq[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    aq[w] = row_a[(size_t)w * row_npad + q] + fw.w[w];
+                uint4 qc = make_uint4(0, 0, 0, 0);
+                if constexpr (OUT == DST_TN93)
+                    qc = reinterpret_cast<const uint4 *>(q_counts)[q];
+                const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
+                                               : (uint64_t)(q - row_begin) * n_cols;
+                uint32_t *racc = acc + (b & 1u) * ACC + rb * W * kPanelCols;
+#pragma unroll
+                for (int j = 0; j < PAIRS; ++j) {
+                    const uint32_t k = 2 * tid + 512 * j;
+                    if (k >= pcols)
+                        break;
+                    const uint32_t t = panel0 + k;
+                    const bool live[2] = {!square || t > q, k + 1 < pcols && (!square || t + 1 > q)};
+                    if (!live[1] && !live[0])
+                        continue;  // square: the whole pair lies at or below the diagonal (accumulators stay 0 there)
+                    uint32_t o[2][NT];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t tot[W];
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            const uint32_t a = racc[w * kPanelCols + k + h];
+                            if (a)
+                                racc[w * kPanelCols + k + h] = 0;
+                            tot[w] = a + ca[j][h][w] + aq[w];
+                        }
+                        P::unpack(tot, o[h]);
+                    }
+                    const uint64_t at = row_at + t;
+                    if constexpr (OUT == OUT_INT) {
+                        int64_t *out = static_cast<int64_t *>(out_v);
+                        if (live[0] && live[1]) {
+                            I64x2 v;
+                            v.a = (int64_t)o[0][0];
+                            v.b = (int64_t)o[1][0];
+                            *reinterpret_cast<I64x2 *>(out + at) = v;
+                        } else if (live[0]) {
+                            out[at] = (int64_t)o[0][0];
+                        } else {
+                            out[at + 1] = (int64_t)o[1][0];
+                        }
+                    } else if constexpr (OUT == OUT_TALLY) {
+                        uint32_t *out = static_cast<uint32_t *>(out_v);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (live[h])
+#pragma unroll
+                                for (int x = 0; x < NT; ++x)
+                                    out[(at + h) * NT + x] = o[h][x];
+                    } else if constexpr (OUT == OUT_TALLY16) {
+                        uint16_t *out = static_cast<uint16_t *>(out_v);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (live[h])
+#pragma unroll
+                                for (int x = 0; x < NT; ++x)
+                                    out[(at + h) * NT + x] = (uint16_t)o[h][x];
+                    } else {
+                        double *out = static_cast<double *>(out_v);
+                        double d[2] = {0.0, 0.0};
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (live[h]) {
+                                uint4 tc = make_uint4(0, 0, 0, 0);
+                                if constexpr (OUT == DST_TN93)
+                                    tc = reinterpret_cast<const uint4 *>(t_counts)[t + h];
+                                d[h] = finalize_pair<OUT>(o[h], qc, tc);
+                            }
+                        if (live[0] && live[1]) {
+                            F64x2 v;
+                            v.a = d[0];
+                            v.b = d[1];
+                            *reinterpret_cast<F64x2 *>(out + at) = v;
+                        } else if (live[0]) {
+                            out[at] = d[0];
+                        } else {
+                            out[at + 1] = d[1];
+                        }
                     }
                 }
-            }
-            __syncthreads();
-        }
-        // ---- C: constants, finalisation, canonical-order store
-        uint32_t aq[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-            aq[w] = row_a[(size_t)w * row_npad + q] + fw.w[w];
-        uint4 qc = make_uint4(0, 0, 0, 0);
-        if constexpr (OUT == DST_TN93)
-            qc = reinterpret_cast<const uint4 *>(q_counts)[q];
-        const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
-                                       : (uint64_t)(q - row_begin) * n_cols;
-        // square: the row's first live column of this panel is q + 1
-        uint32_t k0 = tid;
-        if (square && q + 1 > panel0) {
-            const uint32_t skip = q + 1 - panel0;           // columns [0, skip) of the panel pair with nothing
-            k0 = (skip & ~255u) + tid;
-            if (k0 < skip) k0 += 256;
-        }
-        for (uint32_t k = k0; k < pcols; k += 256) {
-            const uint32_t t = panel0 + k;
-            uint32_t tot[W], o[NT];
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t a = acc[w * kPanelCols + k];
-                if (a)
-                    acc[w * kPanelCols + k] = 0;
-                tot[w] = a + col_a[(size_t)w * col_npad + t] + aq[w];
-            }
-            P::unpack(tot, o);
-            const uint64_t at = row_at + t;
-            if constexpr (OUT == OUT_INT) {
-                static_cast<int64_t *>(out_v)[at] = (int64_t)o[0];
-            } else if constexpr (OUT == OUT_TALLY) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    static_cast<uint32_t *>(out_v)[at * NT + j] = o[j];
-            } else if constexpr (OUT == OUT_TALLY16) {
-                uint16_t *o16 = static_cast<uint16_t *>(out_v);
-                if constexpr (NT == 2) {
-                    reinterpret_cast<uint32_t *>(o16)[at] = o[0] | (o[1] << 16);
-                } else if constexpr (NT == 4) {
-                    reinterpret_cast<uint2 *>(o16)[at] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        o16[at * NT + j] = (uint16_t)o[j];
-                }
-            } else {
-                uint4 tc = make_uint4(0, 0, 0, 0);
-                if constexpr (OUT == DST_TN93)
-                    tc = reinterpret_cast<const uint4 *>(t_counts)[t];
-                static_cast<double *>(out_v)[at] = finalize_pair<OUT>(o, qc, tc);
             }
         }
         __syncthreads();
@@ -508,7 +667,7 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, 512);
     hipLaunchKernelGGL(ref_sample_kernel, dim3((unsigned)set.nchunks), dim3(128), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), (uint32_t)set.n, (uint32_t)set.len,
-                       (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.nib, set.ref.planes,
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
                        reinterpret_cast<unsigned long long *>(set.ref.stats));
     return hipGetLastError();
 }
@@ -555,11 +714,24 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_aconst(const DeviceSet &set, const uint8_t *ref_nib, int family, bool wide,
-                         const ConsensusLut *d_lut, hipStream_t stream)
+hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pad_counts_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, cnt, padded, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, size_t n, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cnt, tab, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream)
 {
     hipLaunchKernelGGL(aconst_kernel, dim3((unsigned)((set.n + 3) / 4)), dim3(256), 0, stream, set.rec.off,
-                       set.rec.ent, ref_nib, d_lut, family, wide ? 1 : 0, family_words(family, wide),
+                       set.rec.ent, d_lut, family, wide ? 1 : 0, family_words(family, wide),
                        (uint32_t)set.n, (uint32_t)set.npad, set.aconst);
     return hipGetLastError();
 }
@@ -570,7 +742,7 @@ template <int FAM, bool WIDE, int OUT>
 hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
     constexpr int W = Pack<FAM, WIDE>::W;
-    const size_t smem = ((size_t)W * kPanelCols + 257 + 256 + 256 + 4) * sizeof(uint32_t);
+    const size_t smem = ((size_t)2 * kAccRows * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1) * sizeof(uint32_t);
     auto kern = consensus_pair_kernel<FAM, WIDE, OUT>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -578,9 +750,9 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(256), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
-                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.off, cl.cols->site.ent,
-                       cl.cols->aconst, (uint32_t)cl.cols->npad, cl.cols->site.n_panels, cl.cols->ref.nib, cl.d_lut,
+    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(512), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
+                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.tab, cl.cols->site.ent,
+                       cl.cols->aconst, (uint32_t)cl.cols->npad, cl.cols->site.n_panels, cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
                        (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0);
     return hipGetLastError();

@@ -45,15 +45,18 @@ constexpr uint32_t kBlockThreads = 256;
 //     F_k    = sum_s f_k(c,c)              A_k(x) = sum over x's difference sites of f_k(x,c) - f_k(c,c)
 //     h_k    = f_k(q,t) - f_k(q,c) - f_k(c,t) + f_k(c,c)
 // exact integers whatever c is; the work is proportional to the differences from c, not to L.
-constexpr uint32_t kPanelCols = 8192;      // column records per site bucket = width of the LDS accumulators
-constexpr uint32_t kEntryShift = 28;       // list entries: (site or record) | nibble << 28
-constexpr uint32_t kEntryMask = (1u << kEntryShift) - 1;
+constexpr uint32_t kPanelCols = 2048;      // column records per site bucket = width of the LDS accumulators
+constexpr int kAccRows = 2;                // rows whose accumulators a workgroup holds at once
+constexpr uint32_t kTileRowsMax = 32;      // rows of one consensus-path tile (a multiple of kAccRows)
+constexpr uint32_t kEntryShift = 28;       // list entries: nibble in the top four bits
+constexpr uint32_t kEntryMask = (1u << kEntryShift) - 1;   // bucket entries: column record | nibble << 28
+constexpr uint32_t kSiteBits = 25;         // record-list entries: site | reference class << 25 | nibble << 28
+constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
 
 struct ConsensusRef {             // the reference sequence, sampled from the set that owns it
-    uint8_t *nib = nullptr;       // [nchunks * 128] nibble per site (8, 4, 2, 1 or 15; 15 beyond len)
-    uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records')
+    uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records'); N past len
     uint64_t *stats = nullptr;    // device: {known sites, sum of deviants, sum of deviants^2, sample size}
     uint64_t h_stats[4] = {0, 0, 0, 0};
     size_t nchunks = 0;
@@ -62,7 +65,7 @@ struct ConsensusRef {             // the reference sequence, sampled from the se
 
 struct RecordIndex {              // per record: the sites where it differs from the reference, ascending
     uint32_t *off = nullptr;      // [n + 1]
-    uint32_t *ent = nullptr;      // site | nibble << 28
+    uint32_t *ent = nullptr;      // site | class of the reference there << 25 | the record's nibble << 28
     size_t off_cap = 0, ent_cap = 0;
     uint64_t total = 0;
     const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
@@ -71,9 +74,11 @@ struct RecordIndex {              // per record: the sites where it differs from
 };
 
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
-    uint32_t *off = nullptr;      // [n_sites * n_panels + 1]
-    uint32_t *ent = nullptr;      // record | nibble << 28 (any order inside a bucket)
-    size_t off_cap = 0, ent_cap = 0;
+    uint32_t *cnt = nullptr;      // [n_sites * n_panels + 1] entries per bucket
+    uint32_t *off = nullptr;      // [n_sites * n_panels + 1] bucket starts: every bucket begins on a 16-byte boundary
+    uint2 *tab = nullptr;         // [n_sites * n_panels] {start, entries}: one 8-byte load per lookup
+    uint32_t *ent = nullptr;      // record | nibble << 28 (any order inside a bucket; padding is never read)
+    size_t cnt_cap = 0, off_cap = 0, tab_cap = 0, ent_cap = 0;
     uint32_t n_panels = 0;
     bool valid = false;
 };
@@ -169,8 +174,10 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, bool fill
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
-hipError_t launch_aconst(const DeviceSet &set, const uint8_t *ref_nib, int family, bool wide, const ConsensusLut *d_lut,
-                         hipStream_t stream);
+hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
+// bucket sizes -> sizes rounded up to 4 entries (scanned next); scanned starts + sizes -> the lookup table
+hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hipStream_t stream);
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, size_t n, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
                                   hipStream_t stream);

@@ -1,7 +1,7 @@
 """GPU (-m gpu): the consensus-delta path (dst_consensus.hip) and the per-alignment precompute of `-m n`
 (consensus(), src/fastaio.rs:289-336; get_differences(), src/fastaio.rs:67-75) against the oracle.
 The general parity suite (test_gpu_parity.py, test_gpu_fuzz.py) already runs every case on this path;
-here are the shapes that are specific to it: panels of 8,192 columns, lists longer than one slice,
+here are the shapes that are specific to it: panels of 2,048 columns, 4-row batches, lists longer than one slice,
 32-bit tallies, shared gap runs, the path choice."""
 import numpy as np
 import pytest
@@ -73,18 +73,18 @@ def test_paths_agree_bit_for_bit_and_report_themselves(eng):
 
 
 def test_column_panels_and_row_tiles(eng):
-    """More than two panels of 8,192 column records; rows that start inside a panel; partial last panel."""
-    n, L = 17000, 400
+    """Many panels of 2,048 column records; rows that start inside a panel; odd and partial last panel."""
+    n, L = 17001, 400
     codes = low_diversity(n, L, 2, subs=5e-3)
     eng.set_path("consensus")
     eng.upload(0, codes)
     rng = np.random.default_rng(4)
-    rows = [0, 1, 7, 8, 8190, 8191, 8192, 8193, 16383, 16384, 16385, n - 2] + [int(x) for x in rng.integers(0, n - 1, 12)]
+    rows = [0, 1, 2, 3, 4, 5, 31, 32, 33, 2046, 2047, 2048, 2049, 4095, 4096, 8191, 8192, 8193, 16383, 16384, 16385, n - 3, n - 2] + [int(x) for x in rng.integers(0, n - 1, 12)]
     pairs = []
     for i in rows:
-        cols = {i + 1, n - 1, min(n - 1, max(i + 1, 8191)), min(n - 1, max(i + 1, 8192)),
+        cols = {i + 1, min(n - 1, i + 2), n - 1, n - 2, min(n - 1, max(i + 1, 2047)), min(n - 1, max(i + 1, 2048)), min(n - 1, max(i + 1, 8192)),
                 min(n - 1, max(i + 1, 16384))} | {int(x) for x in rng.integers(i + 1, n, 6)}
-        pairs += [(i, j) for j in cols]
+        pairs += [(i, j) for j in cols if j > i]
     for m in ("n_high", "raw", "tn93", "k80"):
         sample_check(eng, codes, m, pairs)
     assert eng.last_path() == "consensus"
