@@ -45,20 +45,21 @@ __device__ __forceinline__ uint32_t popc4(uint4 v)
 // =============================================================================================
 // reference sequence: per-site plurality over a sample of the records
 // =============================================================================================
-// One block = one 128-site chunk, one thread = one site.  Every thread of a block reads the same 16
-// bytes of a sampled record (broadcast).  Classes: known A, G, C, T and the N class (N, -, ?); ties go
-// to the first in that order.  Any choice gives exact results — the reference only decides how much
-// work the pair kernel has.
-__global__ __launch_bounds__(128) void ref_sample_kernel(const uint32_t *__restrict__ planes32, uint32_t n,
+// One block = one 128-site chunk: 4 groups of 128 threads, thread = (site, every 4th sample); the groups'
+// class counts meet in LDS.  Every thread of a group reads the same 16 bytes of a sampled record (broadcast).
+// Classes: known A, G, C, T and the N class (N, -, ?); ties go to the first in that order.  Any choice
+// gives exact results — the reference only decides how much work the pair kernel has.
+__global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restrict__ planes32, uint32_t n,
                                                          uint32_t len, uint32_t nchunks, uint32_t npad,
                                                          uint32_t samples, uint4 *__restrict__ ref_planes,
                                                          unsigned long long *__restrict__ stats)
 {
-    const uint32_t c = blockIdx.x, b = threadIdx.x;
+    __shared__ uint32_t part[4][5][128];
+    const uint32_t c = blockIdx.x, b = threadIdx.x & 127u, grp = threadIdx.x >> 7;
     const uint32_t w = b >> 5, bit = b & 31;
     const size_t ps = (size_t)nchunks * npad * 4;  // plane stride in 32-bit words
     uint32_t cnt[5] = {0, 0, 0, 0, 0};
-    for (uint32_t k = 0; k < samples; ++k) {
+    for (uint32_t k = grp; k < samples; k += 4) {
         const uint32_t r = (uint32_t)(((uint64_t)k * n) / samples);
         const size_t at = ((size_t)c * npad + r) * 4 + w;
         const uint32_t A = (planes32[PL_A * ps + at] >> bit) & 1u, G = (planes32[PL_G * ps + at] >> bit) & 1u;
@@ -70,6 +71,15 @@ __global__ __launch_bounds__(128) void ref_sample_kernel(const uint32_t *__restr
         cnt[3] += nib == 1;
         cnt[4] += nib == 15;
     }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        part[grp][k][b] = cnt[k];
+    __syncthreads();
+    if (grp != 0)
+        return;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        cnt[k] = part[0][k][b] + part[1][k][b] + part[2][k][b] + part[3][k][b];
     uint32_t best = cnt[0], cls = 0;
 #pragma unroll
     for (uint32_t k = 1; k < 5; ++k)
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(128) void ref_sample_kernel(const uint32_t *__restr
 // One wave = 8 records x 8 chunks per step (lane = chunk-lane * 8 + record-lane), so the eight lanes of
 // a chunk read one 128-byte line of each plane, and a record's entries come out in ascending site order:
 // the exclusive prefix over the chunk-lanes of a record is three shuffles.
-// FILL == false: rec[r] = list length, site[b] += 1 per entry (b = site * n_panels + r / kPanelCols).
+// FILL == false: rec[r] = list length, site[b] += 1 per entry (b = (r / kPanelCols) * sites + site, sites = nchunks * 128:
+// panel-major, so everything one panel's tiles look up is one contiguous, L2-sized piece).
 // FILL == true : rec = scanned offsets, site = scanned bucket offsets, site_cur = zeroed cursors.
 template <bool FILL>
 __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ planes,
@@ -185,12 +196,12 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                               ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
                         rec_ent[at++] = s | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
                         if (want_sites) {
-                            const size_t bk = (size_t)s * n_panels + panel;
+                            const size_t bk = (size_t)panel * ((size_t)nchunks * kChunkSites) + s;
                             const uint32_t pos = atomicAdd(&site_cur[bk], 1u);
                             site_ent[site[bk] + pos] = r | nib << kEntryShift;
                         }
                     } else if (want_sites) {
-                        atomicAdd(&site[(size_t)s * n_panels + panel], 1u);
+                        atomicAdd(&site[(size_t)panel * ((size_t)nchunks * kChunkSites) + s], 1u);
                     }
                 }
             }
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
     const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint2 *__restrict__ site_tab,
     const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
-    uint32_t n_panels, const ConsensusLut *__restrict__ lut, FWords fw,
+    uint32_t n_sites, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
     const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square)
 {
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
     auto load_bucket = [&](const Entry &en) {
         Bucket bk{0u, 0u, 0u};
         if (en.valid) {
-            const uint2 tab = site_tab[(size_t)(en.e & kSiteMask) * n_panels + tile.panel];
+            const uint2 tab = site_tab[(size_t)tile.panel * n_sites + (en.e & kSiteMask)];
             bk.o0 = tab.x;
             bk.cnt = tab.y;
             bk.meta = en.rb << 8 | ((en.e >> kSiteBits) & 7u) << 4 | (en.e >> kEntryShift);
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(128) void site_hist_kernel(const uint32_t *__restri
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
 {
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, 512);
-    hipLaunchKernelGGL(ref_sample_kernel, dim3((unsigned)set.nchunks), dim3(128), 0, stream,
+    hipLaunchKernelGGL(ref_sample_kernel, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), (uint32_t)set.n, (uint32_t)set.len,
                        (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
                        reinterpret_cast<unsigned long long *>(set.ref.stats));
@@ -752,7 +763,7 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
     }
     hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(512), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
                        cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.tab, cl.cols->site.ent,
-                       cl.cols->aconst, (uint32_t)cl.cols->npad, cl.cols->site.n_panels, cl.d_lut,
+                       cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
                        (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0);
     return hipGetLastError();
