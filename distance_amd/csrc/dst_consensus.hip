@@ -372,7 +372,7 @@ struct __attribute__((packed, aligned(8))) I64x2 {
 // wave that has just issued its result stores cannot consume a younger load before those stores have
 // landed in HBM; the event waves' chains of dependent random loads never queue behind a store this way.
 template <int FAM, bool WIDE, int OUT>
-__global__ __launch_bounds__(512) void consensus_pair_kernel(
+__global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
     const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint2 *__restrict__ site_tab,
     const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
@@ -404,17 +404,22 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
         hlut[k] = (&lut->h[FAM][WIDE ? 1 : 0][0][0][0][0])[(k / W) * kMaxWords + k % W];
     if (threadIdx.x <= trows)
         rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
-    // A(column) of an output thread's column pairs: constant over the rows of the tile
-    uint32_t ca[PAIRS][2][W];
+    // A(column) of an output thread's column pairs: constant over the rows of the tile, kept in registers —
+    // except for tn93, whose finalisation needs the registers more (there the 4 bytes are re-read per pair
+    // and the pair loop stays rolled: one copy of the formula in the code)
+    constexpr bool HOIST = OUT != DST_TN93;
+    uint32_t ca[HOIST ? PAIRS : 1][2][W];
+    if constexpr (HOIST) {
 #pragma unroll
-    for (int j = 0; j < PAIRS; ++j)
+        for (int j = 0; j < PAIRS; ++j)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t k = 2 * tid + 512 * j + h;
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t k = 2 * tid + 512 * j + h;
 #pragma unroll
-            for (int w = 0; w < W; ++w)
-                ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
-        }
+                for (int w = 0; w < W; ++w)
+                    ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+            }
+    }
     __syncthreads();
 
     // ---- event waves: the three stages of A, pipelined in registers across batches (entry of batch b+3,
@@ -557,15 +562,14 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
                 const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
                                                : (uint64_t)(q - row_begin) * n_cols;
                 uint32_t *racc = acc + (b & 1u) * ACC + rb * W * kPanelCols;
-#pragma unroll
-                for (int j = 0; j < PAIRS; ++j) {
+                auto do_pair = [&](int j) {
                     const uint32_t k = 2 * tid + 512 * j;
                     if (k >= pcols)
-                        break;
+                        return;
                     const uint32_t t = panel0 + k;
                     const bool live[2] = {!square || t > q, k + 1 < pcols && (!square || t + 1 > q)};
                     if (!live[1] && !live[0])
-                        continue;  // square: the whole pair lies at or below the diagonal (accumulators stay 0 there)
+                        return;  // square: the whole pair lies at or below the diagonal (accumulators stay 0 there)
                     uint32_t o[2][NT];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -575,7 +579,12 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
                             const uint32_t a = racc[w * kPanelCols + k + h];
                             if (a)
                                 racc[w * kPanelCols + k + h] = 0;
-                            tot[w] = a + ca[j][h][w] + aq[w];
+                            uint32_t cav;
+                            if constexpr (HOIST)
+                                cav = ca[j][h][w];
+                            else
+                                cav = k + h < pcols ? col_a[(size_t)w * col_npad + t + h] : 0u;
+                            tot[w] = a + cav + aq[w];
                         }
                         P::unpack(tot, o[h]);
                     }
@@ -611,14 +620,23 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
                     } else {
                         double *out = static_cast<double *>(out_v);
                         double d[2] = {0.0, 0.0};
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                        auto fin = [&](int h) {
                             if (live[h]) {
                                 uint4 tc = make_uint4(0, 0, 0, 0);
                                 if constexpr (OUT == DST_TN93)
                                     tc = reinterpret_cast<const uint4 *>(t_counts)[t + h];
                                 d[h] = finalize_pair<OUT>(o[h], qc, tc);
                             }
+                        };
+                        if constexpr (OUT == DST_TN93) {
+                            // one copy of the formula, not two: tn93's registers decide how many workgroups fit a CU
+#pragma unroll 1
+                            for (int h = 0; h < 2; ++h)
+                                fin(h);
+                        } else {
+                            fin(0);
+                            fin(1);
+                        }
                         if (live[0] && live[1]) {
                             F64x2 v;
                             v.a = d[0];
@@ -630,6 +648,15 @@ __global__ __launch_bounds__(512) void consensus_pair_kernel(
                             out[at + 1] = d[1];
                         }
                     }
+                };
+                if constexpr (HOIST) {
+#pragma unroll
+                    for (int j = 0; j < PAIRS; ++j)
+                        do_pair(j);
+                } else {
+#pragma unroll 1
+                    for (int j = 0; j < PAIRS; ++j)
+                        do_pair(j);
                 }
             }
         }

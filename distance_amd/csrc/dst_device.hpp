@@ -4,6 +4,7 @@
 // Both files are built with -ffp-contract=off: rustc never fuses a*b+c.
 #pragma once
 #include "dst_internal.h"
+#include "dst_logtab.h"
 
 namespace dst {
 namespace {
@@ -11,6 +12,44 @@ namespace {
 __device__ __forceinline__ uint64_t tri_row_start(uint64_t n, uint64_t i)
 {
     return i * (2 * n - i - 1) / 2;
+}
+
+// ---- natural logarithm for the fused finalisation ------------------------------------------------
+// Table-driven, ~25 f64 instructions against ~90 for the library's: x = 2^k z, z in [0.6875, 1.375) cut into
+// 128 pieces (tools/gen_logtab.py): ln x = k ln2 + logc + log1p(z/c - 1), |z/c - 1| <= 2^-7, Taylor to r^9,
+// the head and the tail of the sum kept apart.  Within 1 ulp of glibc's log (which the reference calls through
+// f64::ln) over [2^-1000, inf); ln(1) = +0 exactly; zeros, negatives, NaN, infinities and values below 2^-1000
+// take the library's path, so NaN / -inf patterns are the library's.
+struct LogEntry {
+    double invc, logc;
+};
+__device__ const LogEntry kLogTab[128] = {DST_LOG_TABLE};
+
+__device__ __attribute__((noinline)) double dst_log_special(double x) { return log(x); }
+
+__device__ __forceinline__ double dst_log(double x)
+{
+    if (!(x >= 0x1p-1000 && x < __builtin_huge_val()))
+        return dst_log_special(x);  // one out-of-line copy of the library's code per kernel, rarely run
+    const uint64_t tmp = (uint64_t)__double_as_longlong(x) - 0x3FE6000000000000ull;
+    const int64_t k = (int64_t)tmp >> 52;
+    const uint64_t m = tmp & 0x000FFFFFFFFFFFFFull;
+    const double z = __longlong_as_double((long long)(0x3FE6000000000000ull + m));
+    const LogEntry e = kLogTab[(uint32_t)(m >> 45)];
+    const double r = fma(z, e.invc, -1.0);
+    const double kd = (double)k;
+    const double w = fma(kd, DST_LN2_HI, e.logc);
+    double q = 1.0 / 9.0;
+    q = fma(q, r, -1.0 / 8.0);
+    q = fma(q, r, 1.0 / 7.0);
+    q = fma(q, r, -1.0 / 6.0);
+    q = fma(q, r, 1.0 / 5.0);
+    q = fma(q, r, -1.0 / 4.0);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -1.0 / 2.0);
+    const double lo = fma(kd, DST_LN2_LO, (r * r) * q);
+    const double hi = w + r;
+    return hi + ((w - hi) + r + lo);
 }
 
 // ---- finalisation math: tallies -> f64 in the reference's operation order ---------------------
@@ -22,19 +61,41 @@ __device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measur
 __device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d)  // src/measures.rs:72-77
 {
     const double p = fin_raw(n, d);
-    return -0.75 * log(1.0 - (4.0 / 3.0) * p);
+    return -0.75 * dst_log(1.0 - (4.0 / 3.0) * p);
+}
+
+// Several correctly rounded quotients over ONE divisor: y = RN(1/b) by a real division, then per numerator
+// Markstein's correction q = RN(a y), r = a - b q (exact in the fma), RN(q + r y) = RN(a/b) — three fused
+// operations instead of a division's ~14, and the same bits (IEEE division is correctly rounded too).  It holds
+// for finite non-zero b whose significand is not all ones, away from overflow / underflow: the callers check
+// once that every divisor is a positive count or frequency sum (integers below 2^34 and their ratios) and
+// send anything else (a record pair without known bases, ...) through the plain formulas.
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+__device__ __attribute__((noinline)) double fin_k80_plain(uint32_t count_L, uint32_t ts, uint32_t tv)
+{
+    const double P = (double)ts / (double)count_L;
+    const double Q = (double)tv / (double)count_L;
+    return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
 }
 
 __device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv)  // :109-112
 {
-    const double P = (double)ts / (double)count_L;
-    const double Q = (double)tv / (double)count_L;
-    return -0.5 * log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
+    if (count_L == 0)
+        return fin_k80_plain(count_L, ts, tv);
+    const double L = (double)count_L, inv_L = 1.0 / L;
+    const double P = div_by((double)ts, L, inv_L);
+    const double Q = div_by((double)tv, L, inv_L);
+    return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
 }
 
 // counts = {A, T, G, C}; sums keep the reference's operand order (target first), :118-190
-__device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
-                                           uint32_t count_P2, uint4 qc, uint4 tc)
+__device__ __attribute__((noinline)) double fin_tn93_plain(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
+                                                           uint32_t count_P2, uint4 qc, uint4 tc)
 {
     const uint64_t L = (uint64_t)qc.x + qc.y + qc.z + qc.w + tc.x + tc.y + tc.z + tc.w;
     const double g_A = ((double)tc.x + (double)qc.x) / (double)L;
@@ -52,7 +113,42 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     const double w1 = 1.0 - P1 / k1 - Q / (2.0 * g_R);
     const double w2 = 1.0 - P2 / k2 - Q / (2.0 * g_Y);
     const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
-    double d = -k1 * log(w1) - k2 * log(w2) - k3 * log(w3);
+    double d = -k1 * dst_log(w1) - k2 * dst_log(w2) - k3 * dst_log(w3);
+    if (d == 0.0)
+        d = 0.0;
+    return d;
+}
+
+// The same values with 7 divisions instead of 18: the quotients over L, count_L, g_R and g_Y share one
+// reciprocal each (div_by).  The integer sums are exact in f64 (< 2^53), so adding them as integers first gives
+// the reference's values.
+__device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
+                                           uint32_t count_P2, uint4 qc, uint4 tc)
+{
+    const uint64_t sA = (uint64_t)tc.x + qc.x, sT = (uint64_t)tc.y + qc.y, sG = (uint64_t)tc.z + qc.z,
+                   sC = (uint64_t)tc.w + qc.w;
+    if (count_L == 0 || sA + sG == 0 || sC + sT == 0)
+        return fin_tn93_plain(count_L, count_d, count_P1, count_P2, qc, tc);
+    const double L = (double)(sA + sT + sG + sC), inv_L = 1.0 / L;
+    const double g_A = div_by((double)sA, L, inv_L);
+    const double g_C = div_by((double)sC, L, inv_L);
+    const double g_G = div_by((double)sG, L, inv_L);
+    const double g_T = div_by((double)sT, L, inv_L);
+    const double g_R = div_by((double)(sA + sG), L, inv_L);
+    const double g_Y = div_by((double)(sC + sT), L, inv_L);
+    const double inv_R = 1.0 / g_R, inv_Y = 1.0 / g_Y;
+    const double k1 = div_by(2.0 * g_A * g_G, g_R, inv_R);
+    const double k2 = div_by(2.0 * g_T * g_C, g_Y, inv_Y);
+    const double k3 = 2.0 * (g_R * g_Y - div_by(g_A * g_G * g_Y, g_R, inv_R) - div_by(g_T * g_C * g_R, g_Y, inv_Y));
+    const double cL = (double)count_L, inv_cL = 1.0 / cL;
+    const double P1 = div_by((double)count_P1, cL, inv_cL);
+    const double P2 = div_by((double)count_P2, cL, inv_cL);
+    const double Q = div_by((double)(count_d - (count_P1 + count_P2)), cL, inv_cL);
+    // Q / (2 g_R) = (Q / g_R) / 2: halving is exact
+    const double w1 = 1.0 - P1 / k1 - 0.5 * div_by(Q, g_R, inv_R);
+    const double w2 = 1.0 - P2 / k2 - 0.5 * div_by(Q, g_Y, inv_Y);
+    const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
+    double d = -k1 * dst_log(w1) - k2 * dst_log(w2) - k3 * dst_log(w3);
     if (d == 0.0)
         d = 0.0;
     return d;

@@ -236,6 +236,54 @@ def test_tally16_and_device_finalize(eng):
         eng.run_square("raw", tallies16=True)       # tallies may exceed 16 bits
 
 
+def test_device_finalisation_over_a_sweep_of_tallies(eng):
+    """The fused finalisation (table-driven dst_log, reference operation order) on tallies chosen to walk the
+    whole range of each formula — p from 0 to past 0.75 (ln's argument through 1, 0 and below), transition /
+    transversion mixes — against the oracle's glibc finalisation: within 1e-12, same NaN / inf / -0 patterns."""
+    import torch
+    n, L = 300, 1000
+    codes = random_alignment(n, L, 77)
+    eng.upload(0, codes)
+    pairs = n * (n - 1) // 2
+    rng = np.random.default_rng(8)
+    counts = oracle.count_bases_matrix(codes)
+    ij = oracle.pairs_square(n)
+    dev = torch.device("cuda", 0)
+    for m in ("raw", "jc69", "k80", "tn93"):
+        w = da.tally_width(m)
+        t = np.zeros((pairs, w), np.uint32)
+        d = rng.integers(1, 60000, pairs)
+        d[:50] = np.arange(50)                                   # d = 0 (0/0), tiny denominators
+        frac = rng.random(pairs)
+        frac[:2000] = np.linspace(0.0, 1.0, 2000)                # p sweeps 0 .. 1, through 0.75
+        frac[2000:2400] = 0.75 + (rng.random(400) - 0.5) * 1e-3
+        frac[2400:2600] = rng.random(200) * 1e-4                 # ln's argument next to 1
+        if m in ("raw", "jc69"):
+            t[:, 1] = d
+            t[:, 0] = np.minimum(d, np.round(frac * d)).astype(np.uint32)
+            t[2600:2700, 0] = 0                                  # p = 0: -0.0 for jc69
+            t[2700:2800, 0] = (3 * (d[2700:2800] // 4)).astype(np.uint32)
+            t[2700:2800, 1] = (4 * (d[2700:2800] // 4)).astype(np.uint32)   # p = 0.75 exactly: +inf
+        elif m == "k80":
+            diff = np.minimum(d, np.round(frac * d)).astype(np.int64)
+            ts = (diff * rng.random(pairs)).astype(np.int64)
+            t[:, 0], t[:, 1], t[:, 2] = d, ts, diff - ts
+        else:
+            diff = np.minimum(d, np.round(frac * d)).astype(np.int64)
+            p1 = (diff * rng.random(pairs) * 0.5).astype(np.int64)
+            p2 = ((diff - p1) * rng.random(pairs) * 0.6).astype(np.int64)
+            t[:, 0], t[:, 1], t[:, 2], t[:, 3] = d, diff, p1, p2
+        d_t = torch.from_numpy(t).to(dev)
+        d_o = torch.empty(pairs, dtype=torch.float64, device=dev)
+        eng.finalize_device(m, 0, n, d_t.data_ptr(), d_o.data_ptr(), pairs * 8, tally_kind=da.OUT_TALLY)
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy()
+        want = np.array([oracle.finalize(m, t[k], counts[int(ij[k][0])], counts[int(ij[k][1])]) for k in range(pairs)])
+        assert_close(got, want)
+        zero = want == 0.0
+        assert np.array_equal(np.signbit(got[zero]), np.signbit(want[zero])), m     # -0.0 where the reference has it
+
+
 def test_in_order_slab_sink(eng):
     """dst_run_slabs: slabs arrive strictly in canonical order and concatenate to the full result."""
     a = random_alignment(150, 400, 33)

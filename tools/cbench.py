@@ -50,6 +50,7 @@ for m in args.measures.split(","):
                 step.append(dt * 1e3)
                 kern.append(eng.last_kernel_ms()["pair_ms"])
         chk = float(torch.nan_to_num(out.view(torch.float64) if m not in da.INT_MEASURES else out.view(torch.int64).double()).sum())
+        bits = int(out.view(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF     # exact, order-free: any changed bit shows
         print(f"{m:7s} {path:10s} used={eng.last_path():10s} step {np.median(step):9.3f} ms  pair kernel {np.median(kern):9.3f} ms"
-              f"  {pairs / np.median(step) * 1e3:.3e} pairs/s  checksum {chk:.6f}")
+              f"  {pairs / np.median(step) * 1e3:.3e} pairs/s  checksum {chk:.6f} bits {bits:016x}")
 eng.close()
