@@ -328,23 +328,34 @@ def main():
     # so it gets a smaller share of the pair space.  The pair rate that sizes the share is MEASURED here: every
     # rank times one run of an equal-split slab on the path it will use, the mean goes to all ranks.
     first_share = None
-    if wire16:
-        eq_bounds, eq_offs = slab_layout(n, world, square=True)
-        probe_pairs = eq_offs[rank + 1] - eq_offs[rank]
-        probe = torch.empty((max(probe_pairs, 1), 2 * width), dtype=torch.uint8, device=dev)
-        eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+    # Calibration (untimed): every rank runs one equal-split slab, upload included, on each kernel path; the faster
+    # path overall is then set explicitly (the library's own per-launch choice would charge the cost of building the
+    # difference lists to every sub-slab launch, although one build per step serves all of them), and its MEASURED
+    # pair rate sizes rank 0's share below.
+    eq_bounds, eq_offs = slab_layout(n, world, square=True)
+    probe_pairs = eq_offs[rank + 1] - eq_offs[rank]
+    probe_kind = da.OUT_TALLY16 if wire16 else da.OUT_DISTANCE
+    probe = torch.empty(max(probe_pairs, 1) * (2 * width if wire16 else 8), dtype=torch.uint8, device=dev)
+    probe_s = {}
+    for path in (["dense", "consensus"] if args.path == "auto" else [args.path]):
+        eng.set_path(path)
         for _ in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
             eng.run_square_device(measure, eq_bounds[rank], eq_bounds[rank + 1], probe.data_ptr(), probe.numel(),
-                                  stream=stream, out_kind=da.OUT_TALLY16)
+                                  stream=stream, out_kind=probe_kind)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        rate = torch.tensor([probe_pairs / max(dt, 1e-9)], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
-        dist.all_reduce(rate)
-        pair_rate = float(rate.item()) / world
+            probe_s[path] = time.perf_counter() - t0
+    del probe
+    names = sorted(probe_s)
+    tt = torch.tensor([probe_s[k] for k in names], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
+    dist.all_reduce(tt)
+    best = names[int(torch.argmin(tt).item())]
+    eng.set_path(best)
+    pair_rate = total_pairs / world / (float(tt.min().item()) / world)
+    if wire16:
         first_share = root_share(world, (2 * width + 8) / 4.5e12 * pair_rate)
-        del probe
     bounds, offsets = slab_layout(n, world, square=True, first_share=first_share)
     my_pairs = offsets[rank + 1] - offsets[rank]
     chunks = args.chunks
@@ -466,6 +477,7 @@ def main():
                        "partition": f"{world} contiguous row ranges of equal pair count"
                                     + (f" (rank 0: {first_share:.4f} of the pairs — it also finalises the gathered tallies; "
                                        f"share sized from the measured {pair_rate:.3e} pairs/s per rank)" if first_share else "")
+                                    + f"; kernel path {best} picked by a timed probe of both ({', '.join(f'{k} {1e3 * v:.2f} ms' for k, v in probe_s.items())} on rank 0)"
                                     + f", {chunks} sub-slabs each, sends overlapped with compute, "
                                     + ("uint16 tallies" if wire16 else "f64") + " on the wire",
                        "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
