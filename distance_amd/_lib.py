@@ -74,6 +74,11 @@ _SIGS = {
     "dst_stream_collect": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "dst_stream_in_flight": (C.c_int, [_vp]),
     "dst_stream_close": (C.c_int, [_vp]),
+    "dst_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "dst_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dst_comm_destroy": (C.c_int, [_vp]),
+    "dst_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dst_gather_slabs": (C.c_int, [_vp, _vp, _vp, _u64p, _u64p, C.c_int, _vp]),
     "dst_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "dst_host_free": (C.c_int, [_vp]),
     "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),

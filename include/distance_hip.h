@@ -193,6 +193,30 @@ int dst_stream_collect(dst_stream *stream, size_t *n_records, const void **resul
 int dst_stream_in_flight(const dst_stream *stream);   /* submitted, not yet collected */
 int dst_stream_close(dst_stream *stream);
 
+/* ---- multi-GPU: the gather of the result slabs (one process per GPU, RCCL over xGMI) --------- */
+/* The pair space shards by contiguous canonical ranges (dst_partition_square / dst_partition_rect): every rank
+ * uploads the whole set, runs its own row range, and the only exchange is this gather into ONE rank's buffer
+ * — what gather_write consumes (src/lib.rs:612-644).  Grouped ncclSend / ncclRecv straight from each rank's slab
+ * into its place in the root's buffer (peer -> root on all xGMI links at once; no ring, no staging).  RCCL is
+ * loaded on first use (librccl.so.1); single-GPU hosts never touch it.
+ * Bootstrap: rank 0 calls dst_comm_unique_id and hands the DST_COMM_ID_BYTES bytes to the other ranks by whatever
+ * its launcher offers (environment, file, MPI ...); then every rank calls dst_comm_create (collective). */
+#define DST_COMM_ID_BYTES 128
+typedef struct dst_comm dst_comm;
+int dst_comm_unique_id(uint8_t *id, size_t cap);
+int dst_comm_create(dst_ctx *ctx, const uint8_t *id, int rank, int world, dst_comm **comm);
+int dst_comm_destroy(dst_comm *comm);
+int dst_comm_info(const dst_comm *comm, int *rank, int *world);
+/* Collective.  byte_offsets / byte_sizes have `world` entries and are the same on every rank: rank r contributes
+ * byte_sizes[r] bytes from its d_local, which land at d_full + byte_offsets[r] on `root` (d_full may be NULL on
+ * the other ranks; the root's own slab is copied only if it is not already in place).  Any payload: f64 / int64
+ * results, or DST_OUT_TALLY16 tallies that the root then finalises with dst_finalize_device.  A rank's range may
+ * be sent in several calls (sub-slabs): the transfer of sub-slab k runs on `stream` behind what is already queued
+ * there, so the next dst_run_square on another stream overlaps it.  Asynchronous on `stream` (hipStream_t;
+ * NULL = the context's stream, then the call waits). */
+int dst_gather_slabs(dst_comm *comm, const void *d_local, void *d_full, const uint64_t *byte_offsets,
+                     const uint64_t *byte_sizes, int root, void *stream);
+
 /* In-order sink (the shape of gather_write's input, src/lib.rs:612-644): the run is cut into row
  * slabs of at most max_pairs pairs (>= one row each) and `sink` is called once per slab, strictly
  * in canonical order, on the calling thread, with the slab's results in library-owned pinned host

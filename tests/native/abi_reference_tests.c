@@ -132,6 +132,83 @@ int main(void)
     OK(dst_upload(ctx, 0, &f1[0][0], 2, 6, 6, NULL));
     CHECK(dst_run_square_host(ctx, DST_RAW, 0, 2, DST_OUT_DISTANCE, &d, 4) == DST_ERR_CAPACITY);
     CHECK(dst_run_square_host(ctx, 17, 0, 2, DST_OUT_DISTANCE, &d, sizeof d) == DST_ERR_ARG);
+
+    /* ---- the per-alignment precompute of -m n on the device --------------------------------------------- */
+    /* test_consensus (fastaio.rs:424-454): {FASTA, OTHER} -> FASTA's codes (1-1 ties at sites 2, 5 resolve to G);
+     * {OTHER, OTHER} -> OTHER's codes */
+    uint8_t two[2][15], cons[15];
+    encode(TARGET, two[0]);
+    encode(QUERY, two[1]);
+    OK(dst_upload(ctx, 0, &two[0][0], 2, 15, 15, NULL));
+    OK(dst_consensus(ctx, 0, cons, sizeof cons));
+    CHECK(memcmp(cons, two[0], 15) == 0);
+    memcpy(two[0], two[1], 15);
+    OK(dst_upload(ctx, 0, &two[0][0], 2, 15, 15, NULL));
+    OK(dst_consensus(ctx, 0, cons, sizeof cons));
+    CHECK(memcmp(cons, two[1], 15) == 0);
+    /* test_get_differences (fastaio.rs:369-377): FASTA vs OTHER -> [2, 5] */
+    encode(TARGET, two[0]);
+    OK(dst_upload(ctx, 0, &two[0][0], 1, 15, 15, NULL));
+    uint64_t offs[2], total = 0;
+    uint32_t sites[15];
+    OK(dst_differences(ctx, 0, two[1], 15, offs, sites, 15, &total));
+    CHECK(total == 2 && offs[0] == 0 && offs[1] == 2 && sites[0] == 2 && sites[1] == 5);
+
+    /* ---- both kernel paths give the reference's integers (test_snp, test_snp_consensus) ---------------- */
+    encode(TARGET, two[0]);
+    encode(QUERY, two[1]);
+    OK(dst_upload(ctx, 0, &two[0][0], 2, 15, 15, NULL));
+    for (int path = DST_PATH_AUTO; path <= DST_PATH_CONSENSUS; ++path) {
+        OK(dst_set_path(ctx, path));
+        d_int = -1;
+        OK(dst_run_square_host(ctx, DST_N, 0, 2, DST_OUT_DISTANCE, &d_int, sizeof d_int));
+        CHECK(d_int == 2);
+        OK(dst_run_square_host(ctx, DST_TN93, 0, 2, DST_OUT_TALLY, t4, sizeof t4));
+        CHECK(t4[0] == 15 && t4[1] == 2 && t4[2] == 0 && t4[3] == 0);
+        if (path != DST_PATH_AUTO)
+            CHECK(dst_last_path(ctx) == path);
+    }
+    OK(dst_set_path(ctx, DST_PATH_AUTO));
+
+    /* ---- stream mode through the overlapped pipeline: test_integration_2 (lib.rs:1000-1060) ------------- */
+    OK(dst_upload(ctx, 0, &f1[0][0], 2, 6, 6, NULL));
+    dst_stream *st = NULL;
+    OK(dst_stream_open(ctx, DST_N_HIGH, DST_OUT_DISTANCE, 4, 2, &st));
+    uint8_t *buf = NULL;
+    size_t pitch = 0, n_rec = 0;
+    const void *res = NULL;
+    OK(dst_stream_acquire(st, &buf, &pitch, NULL));
+    CHECK(pitch >= 6);
+    encode("ATGATG", buf); /* seqA */
+    OK(dst_stream_submit(st, 1, 0));
+    CHECK(dst_stream_in_flight(st) == 1);
+    OK(dst_stream_collect(st, &n_rec, &res));
+    CHECK(n_rec == 1 && ((const int64_t *)res)[0] == 0 && ((const int64_t *)res)[1] == 1); /* seq1 seqA 0 / seq2 seqA 1 */
+    OK(dst_stream_close(st));
+
+    /* ---- the gather of result slabs: a one-rank communicator (RCCL itself needs one GPU per rank) ------- */
+    {
+        uint8_t id[DST_COMM_ID_BYTES];
+        dst_comm *comm = NULL;
+        OK(dst_comm_unique_id(id, sizeof id));
+        OK(dst_comm_create(ctx, id, 0, 1, &comm));
+        int rank = -1, world = -1;
+        OK(dst_comm_info(comm, &rank, &world));
+        CHECK(rank == 0 && world == 1);
+        void *d_local = NULL, *d_full = NULL;
+        /* device buffers through the run API: rows [0,2) of the 2-record set = 1 pair */
+        CHECK(dst_host_alloc(16, &d_local) == DST_OK); /* pinned host memory is device-accessible: good enough as a slab */
+        CHECK(dst_host_alloc(16, &d_full) == DST_OK);
+        ((int64_t *)d_local)[0] = 42;
+        ((int64_t *)d_full)[0] = -1;
+        const uint64_t goff[1] = {0}, gsize[1] = {8};
+        OK(dst_gather_slabs(comm, d_local, d_full, goff, gsize, 0, NULL));
+        CHECK(((int64_t *)d_full)[0] == 42);
+        CHECK(dst_gather_slabs(comm, d_local, d_full, goff, gsize, 3, NULL) == DST_ERR_ARG);
+        dst_host_free(d_local);
+        dst_host_free(d_full);
+        OK(dst_comm_destroy(comm));
+    }
     OK(dst_destroy(ctx));
     if (!failures)
         puts("abi_reference_tests: all checks passed");
