@@ -24,6 +24,7 @@
 #include <functional>
 #include <future>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -918,30 +919,166 @@ int main(int argc, char **argv)
             reader_done = true;
             qcv.notify_all();
         });
-        for (;;) {
+        // Batches go round-robin to the GPUs (batch b -> GPU b mod G), each GPU runs them through its own
+        // overlapped pipeline (dst_stream_*: page-locked ring slots; H2D of the next batch and D2H of the previous
+        // one under the compare of the current one), the worker formats what it collects, and the main thread
+        // writes the batches strictly in input order (gather_write's idx re-ordering, src/lib.rs:616-637).
+        constexpr int kDepth = 3;
+        struct Item {
+            size_t idx;
             std::unique_ptr<Alignment> batch;
-            {
-                std::unique_lock<std::mutex> lk(qmu);
-                qcv.wait(lk, [&] { return !queue.empty() || reader_done; });
-                if (queue.empty())
-                    break;
-                batch = std::move(queue.front());
-                queue.pop_front();
+        };
+        std::vector<std::deque<Item>> gq((size_t)G);       // per-GPU input queues (guarded by qmu)
+        std::vector<bool> gdone((size_t)G, false);
+        std::map<size_t, std::vector<TextBuf>> done_text;   // formatted batches waiting for the writer
+        std::mutex wmu;
+        std::condition_variable wcv;
+        size_t next_to_write = 0, n_batches = 0;
+        bool all_dispatched = false;
+        const size_t window = (size_t)G * (kDepth + 2);     // bound on batches between dispatch and write
+        std::vector<dst_stream *> streams((size_t)G, nullptr);
+        for (int g = 0; g < G; ++g)
+            gpus[g].check(dst_stream_open(gpus[g].h, measure, DST_OUT_TALLY, batch_records, kDepth, &streams[g]), "stream open");
+        auto gpu_stream_worker = [&](int g) {
+            std::deque<Item> inflight;
+            auto collect_one = [&]() {
+                size_t n_rec = 0;
+                const void *res = nullptr;
+                gpus[g].check(dst_stream_collect(streams[g], &n_rec, &res), "stream collect");
+                Item it = std::move(inflight.front());
+                inflight.pop_front();
+                Job sj = job;
+                sj.square = false;
+                sj.swap_ids = true;          // id1 = loaded record, id2 = streamed record (src/lib.rs:327-330)
+                sj.rows = it.batch.get();    // streamed record outer ...
+                sj.cols = &ref;              // ... loaded record inner (src/lib.rs:323-324)
+                sj.row_counts = measure == DST_TN93 ? it.batch->counts.data() : nullptr;
+                sj.col_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
+                Slab slab;
+                slab.rb = 0;
+                slab.re = it.batch->n;
+                slab.tallies = const_cast<uint32_t *>(static_cast<const uint32_t *>(res));  // library-owned, read only
+                format_slab(sj, slab);
+                {
+                    std::lock_guard<std::mutex> lk(wmu);
+                    done_text[it.idx] = std::move(slab.text);
+                }
+                wcv.notify_all();
+            };
+            for (;;) {
+                Item it;
+                bool have = false;
+                {
+                    std::unique_lock<std::mutex> lk(qmu);
+                    qcv.wait(lk, [&] { return !gq[(size_t)g].empty() || gdone[(size_t)g]; });
+                    if (!gq[(size_t)g].empty()) {
+                        it = std::move(gq[(size_t)g].front());
+                        gq[(size_t)g].pop_front();
+                        have = true;
+                    }
+                }
                 qcv.notify_all();
+                if (!have)
+                    break;
+                if (inflight.size() == (size_t)kDepth - 1)
+                    collect_one();
+                uint8_t *buf = nullptr;
+                size_t pitch = 0;
+                uint32_t *cbuf = nullptr;
+                gpus[g].check(dst_stream_acquire(streams[g], &buf, &pitch, &cbuf), "stream acquire");
+                const Alignment &al = *it.batch;
+                for (size_t r = 0; r < al.n; ++r)
+                    std::memcpy(buf + r * pitch, al.codes.data() + r * al.width, al.width);
+                if (measure == DST_TN93)
+                    std::memcpy(cbuf, al.counts.data(), al.n * 4 * sizeof(uint32_t));
+                gpus[g].check(dst_stream_submit(streams[g], al.n, measure == DST_TN93 ? 1 : 0), "stream submit");
+                inflight.push_back(std::move(it));
             }
-            for (int g = 0; g < G; ++g)
-                gpus[g].check(dst_upload(gpus[g].h, 1, batch->codes.data(), batch->n, batch->width, batch->width,
-                                         measure == DST_TN93 ? batch->counts.data() : nullptr),
-                              "upload batch");
-            Job sj = job;
-            sj.square = false;
-            sj.swap_ids = true;          // id1 = loaded record, id2 = streamed record (src/lib.rs:327-330)
-            sj.rows = batch.get();       // streamed record outer ...
-            sj.cols = &ref;              // ... loaded record inner (src/lib.rs:323-324)
-            sj.row_counts = measure == DST_TN93 ? batch->counts.data() : nullptr;
-            sj.col_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
-            run_slabs(gpus, sj, 1, 0, a.slab_pairs, wr);
+            while (!inflight.empty())
+                collect_one();
+        };
+        std::vector<std::thread> workers;
+        for (int g = 0; g < G; ++g)
+            workers.emplace_back(gpu_stream_worker, g);
+        // dispatcher: the reader's batches, in order, to the GPUs
+        std::thread dispatcher([&] {
+            for (;;) {
+                std::unique_ptr<Alignment> batch;
+                {
+                    std::unique_lock<std::mutex> lk(qmu);
+                    qcv.wait(lk, [&] { return !queue.empty() || reader_done; });
+                    if (queue.empty())
+                        break;
+                    batch = std::move(queue.front());
+                    queue.pop_front();
+                }
+                qcv.notify_all();
+                // a parsed block may hold more records than one pipeline slot: cut it into batches
+                for (size_t r0 = 0; r0 < batch->n; r0 += batch_records) {
+                    std::unique_ptr<Alignment> piece;
+                    if (r0 == 0 && batch->n <= batch_records) {
+                        piece = std::move(batch);
+                    } else {
+                        const size_t r1 = std::min(batch->n, r0 + batch_records);
+                        piece = std::make_unique<Alignment>();
+                        piece->n = r1 - r0;
+                        piece->width = batch->width;
+                        piece->ids.assign(batch->ids.begin() + (long)r0, batch->ids.begin() + (long)r1);
+                        piece->codes.assign(batch->codes.begin() + (long)(r0 * batch->width),
+                                            batch->codes.begin() + (long)(r1 * batch->width));
+                        if (!batch->counts.empty())
+                            piece->counts.assign(batch->counts.begin() + (long)(4 * r0), batch->counts.begin() + (long)(4 * r1));
+                    }
+                    size_t idx;
+                    {   // keep the number of batches between dispatch and write bounded (memory)
+                        std::unique_lock<std::mutex> lk(wmu);
+                        wcv.wait(lk, [&] { return n_batches < next_to_write + window; });
+                        idx = n_batches++;
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(qmu);
+                        gq[idx % (size_t)G].push_back(Item{idx, std::move(piece)});
+                    }
+                    qcv.notify_all();
+                    if (!batch)
+                        break;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                for (int g = 0; g < G; ++g)
+                    gdone[(size_t)g] = true;
+            }
+            qcv.notify_all();
+            {
+                std::lock_guard<std::mutex> lk(wmu);
+                all_dispatched = true;
+            }
+            wcv.notify_all();
+        });
+        for (;;) {  // ordered writer
+            std::vector<TextBuf> text;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return done_text.count(next_to_write) || (all_dispatched && next_to_write >= n_batches); });
+                if (!done_text.count(next_to_write))
+                    break;
+                text = std::move(done_text[next_to_write]);
+                done_text.erase(next_to_write);
+            }
+            for (const TextBuf &part : text)
+                wr.write(part.p.get(), part.len);
+            {
+                std::lock_guard<std::mutex> lk(wmu);
+                ++next_to_write;
+            }
+            wcv.notify_all();
         }
+        dispatcher.join();
+        for (auto &t : workers)
+            t.join();
+        for (int g = 0; g < G; ++g)
+            dst_stream_close(streams[g]);
         reader_thread.join();
         if (record_counter == 0)
             die_message("Empty FASTA file");  // src/fastaio.rs:281-283

@@ -191,12 +191,22 @@ int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64
         for (size_t k = 1; k < ctx->schedules.size(); ++k)
             if (ctx->schedules[k].last_use < ctx->schedules[victim].last_use)
                 victim = k;
-        if (ctx->schedules[victim].d_blocks)
-            HIP_TRY(ctx, hipFree(ctx->schedules[victim].d_blocks));
+        // its buffer is recycled when it is big enough (row slabs of one run have similar tile counts)
+        void *spare = ctx->schedules[victim].d_blocks;
+        const size_t spare_bytes = ctx->schedules[victim].bytes;
         ctx->schedules.erase(ctx->schedules.begin() + (long)victim);
+        if (spare && spare_bytes >= bytes && count) {
+            s.d_blocks = spare;
+            s.bytes = spare_bytes;
+        } else if (spare) {
+            HIP_TRY(ctx, hipFree(spare));
+        }
     }
     if (count) {
-        HIP_TRY(ctx, hipMalloc(&s.d_blocks, bytes));
+        if (!s.d_blocks) {
+            s.bytes = bytes + bytes / 4;
+            HIP_TRY(ctx, hipMalloc(&s.d_blocks, s.bytes));
+        }
         // pageable source: the copy is complete on return, later kernels on any stream see it
         HIP_TRY(ctx, hipMemcpy(s.d_blocks, src, bytes, hipMemcpyHostToDevice));
     }
@@ -573,15 +583,18 @@ int run_host(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot,
     if (!h_out)
         return fail(ctx, DST_ERR_ARG, "null output pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    void *d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_out, bytes));
-    int rc = run_common(ctx, measure, square, row_slot, col_slot, rb, re, out_kind, d_out, bytes, nullptr);
+    // one grow-only device buffer per context for the host-buffer forms (no allocation per call)
+    int rc = ensure_bytes(ctx, &ctx->host_out, &ctx->host_out_bytes, bytes);
+    if (rc)
+        return rc;
+    rc = run_common(ctx, measure, square, row_slot, col_slot, rb, re, out_kind, ctx->host_out, bytes, (void *)ctx->stream);
     if (rc == DST_OK) {
-        hipError_t e = hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpyAsync(h_out, ctx->host_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess)
             rc = fail_hip(ctx, e, "hipMemcpy(D2H results)");
     }
-    (void)hipFree(d_out);
     return rc;
 }
 
@@ -664,7 +677,7 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
-    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur})
+    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur, ctx->host_out})
         if (b)
             (void)hipFree(b);
     if (ctx->scratch)
@@ -739,7 +752,15 @@ int dst_upload(dst_ctx *ctx, int slot, const uint8_t *codes, size_t n, size_t le
         d_counts = reinterpret_cast<uint32_t *>(ctx->stage + std::max<size_t>(pitch * n, 128));
         HIP_TRY(ctx, hipMemcpyAsync(d_counts, base_counts, n * 16, hipMemcpyHostToDevice, ctx->stream));
     }
-    return pack_from_device(ctx, slot, ctx->stage, n, len, pitch, d_counts, ctx->stream);
+    rc = pack_from_device(ctx, slot, ctx->stage, n, len, pitch, d_counts, ctx->stream);
+    // the bytes are not needed once they are packed: a large staging buffer (a whole loaded set) is given back, a
+    // small one (streamed batches) is kept for the next upload
+    if (ctx->stage_bytes > ((size_t)256 << 20)) {
+        (void)hipFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_bytes = 0;
+    }
+    return rc;
 }
 
 int dst_upload_device(dst_ctx *ctx, int slot, const void *d_codes, size_t n, size_t len,

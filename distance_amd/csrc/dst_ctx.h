@@ -24,6 +24,7 @@ struct dst_ctx {
         int bm = 0, bn = 0;  // dense tile shape; consensus-path tile lists: bm = rows per tile, bn = -1
         uint32_t nblocks = 0;
         void *d_blocks = nullptr;
+        size_t bytes = 0;  // capacity of d_blocks
         uint64_t last_use = 0;
     };
     std::vector<Schedule> schedules;
@@ -38,6 +39,8 @@ struct dst_ctx {
     size_t scan_tmp_bytes = 0;
     uint32_t *site_cur = nullptr;
     size_t site_cur_bytes = 0;
+    void *host_out = nullptr;  // device staging of the *_host run forms (grow-only)
+    size_t host_out_bytes = 0;
     int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
     uint32_t *scratch = nullptr;  // partial-tally meeting buffer of split-L f64 runs
     size_t scratch_bytes = 0;

@@ -109,6 +109,29 @@ def test_several_contexts_keep_canonical_order(tmp_path):
     assert cli(["-m", "k80", "-i", str(fa), "-s", str(fb), "--devices", "0,0", "--slab-pairs", "700"]) == one
 
 
+def test_stream_batches_sharded_over_contexts(tmp_path):
+    """Stream mode: 41 streamed records in batches of 2 dealt round-robin to three contexts, each with its own
+    overlapped pipeline (dst_stream_*); output in input order; tn93 with lower-case streamed letters."""
+    a = random_alignment(30, 500, seed=21)
+    b = random_alignment(41, 500, seed=22)
+    ida, idb = [f"a{i}" for i in range(len(a))], [f"b{i}" for i in range(len(b))]
+    fa, fb = tmp_path / "a.fasta", tmp_path / "b.fasta"
+    rng = np.random.default_rng(2)
+    tb = to_text(b, rng, lower_frac=0.4)
+    write_fasta(fa, ida, to_text(a))
+    write_fasta(fb, idb, tb, width=70)
+    ca = oracle.count_bases_matrix(a)
+    cb = np.stack([oracle.encode_count_bases(s.encode())[1] for s in tb])
+    for m in ("n_high", "tn93"):
+        d = oracle.all_pairs_rect(m, a, b, counts_a=ca, counts_b=cb) if m == "tn93" else oracle.all_pairs_rect(m, a, b)
+        ij = [(i, j) for j in range(len(b)) for i in range(len(a))]
+        vals = [int(d[i, j]) if m in oracle.INT_MEASURES else d[i, j] for i, j in ij]
+        want = oracle.tsv(ida, idb, ij, vals)
+        for extra in (["--slab-pairs", "60"], ["--slab-pairs", "60", "--devices", "0,0,0", "-t", "3"], []):
+            assert cli(["-m", m, "-i", str(fa), "-s", str(fb)] + extra) == want, (m, extra)
+        assert cli(["-m", m, "-i", str(fa), "-s", "-"], stdin=open(fb, "rb").read()) == want
+
+
 def test_default_measure_is_raw(tmp_path):
     codes = random_alignment(9, 100, seed=5)
     ids = [f"s{i}" for i in range(9)]
