@@ -360,29 +360,31 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
     return DST_OK;
 }
 
-// Which path is cheaper for this launch?  The sampled reference gives, per site, the fraction p_s of
-// records that deviate from it: a pair costs the dense path L sites whatever the data, and the consensus
-// path one output plus about sum_s p_s^2 intersection events.  Constants: measured on MI355X
-// (profiles/r02/consensus_calibration.txt), seconds.
+// Which path is cheaper for this launch?  The sampled reference gives, per site, the fraction p_s of records
+// that deviate from it: a pair costs the dense path L sites whatever the data, and the consensus path one
+// output plus about sum_s p_s^2 intersection events.  Constants: measured on MI355X, seconds
+// (tools/calibrate.py, profiles/r02/consensus_calibration.txt): dense site-pairs per second per measure, the
+// consensus path's time per pair with no events (output-bound: n / n_high / raw; finalisation-bound: the
+// others), time per event, and the list build.
 bool consensus_is_cheaper(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles)
 {
-    static const double dense_site_pairs_per_s[4] = {2.9e14, 1.95e14, 1.6e14, 1.45e14};
-    static const double out_s_per_pair[4] = {2.5e-12, 3.0e-12, 5e-12, 1.3e-11};
-    constexpr double event_s = 4e-11;
-    const int fam = family_of(measure);
+    //                                            n       n_high  raw      jc69     k80      tn93
+    static const double dense_site_pairs_per_s[6] = {2.9e14, 2.9e14, 1.95e14, 1.92e14, 1.82e14, 1.48e14};
+    static const double out_s_per_pair[6] = {2.2e-12, 2.2e-12, 2.3e-12, 3.9e-12, 5.0e-12, 1.55e-11};
+    constexpr double event_s = 4.5e-12;
     const double S = (double)std::max<uint64_t>(cols.ref.h_stats[3], 1);
-    const double events_per_pair = (double)cols.ref.h_stats[2] / (S * S);
+    // the sample's sum of squared deviant counts over-states sum p^2 by about (mean list length) / S
     const double mean_list = (double)cols.ref.h_stats[1] / S;  // differences per record
-    const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[fam];
-    // building the lists reads the planes twice; walking a row's list costs one bucket lookup per panel
+    const double events_per_pair = (double)cols.ref.h_stats[2] / (S * S);
+    const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[measure];
+    // building the lists reads four bit-planes twice; walking a row's list costs one bucket lookup per panel
     const double build = (rows.rec.valid && cols.site.valid) ? 0.0
-                                                              : (double)(rows.n + cols.n) * (double)cols.len * 1.5e-12 + 2e-4;
-    const double walk = (double)ntiles * kConsensusRowsPerTile * mean_list * 2e-9 / 256.0;
-    const double cons = (double)pairs * (out_s_per_pair[fam] + events_per_pair * event_s) + build + walk + 3e-5;
+                                                              : (double)(rows.n + cols.n) * (double)cols.len * 0.5e-12 + 1.5e-4;
+    const double walk = (double)ntiles * kConsensusRowsPerTile * mean_list * 1e-9 / 256.0;
+    const double cons = (double)pairs * (out_s_per_pair[measure] + events_per_pair * event_s) + build + walk + 3e-5;
     return cons < dense;
 }
 
-// the common run: rows [rb, re) of `rows` against every (square: later) record of `cols`
 int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot, uint64_t rb,
                uint64_t re, int out_kind, void *d_out, size_t cap, void *stream_v)
 {
