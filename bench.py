@@ -53,6 +53,10 @@ OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  
 # Measured issue ceiling of the dense raw step (1 v_and + 4 v_bitop3 + 2 v_bcnt on VGPRs only, 8 waves/SIMD,
 # no memory traffic): tools/ubench/ifetch.hip / order.hip, profiles/r01/ubench_rawstep.txt
 RAW_STEP_CEILING_NS = 10.6
+# consensus path: f64 VALU instructions of the fused finalisation per pair (ISA of consensus_pair_kernel: conversions,
+# the expanded division sequences, dst_log's polynomial), and the f64 vector peak in fma lanes per second
+F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 14, "jc69": 45, "k80": 80, "tn93": 250}
+F64_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
 
 
 def host_threads() -> int:
@@ -260,12 +264,27 @@ def main():
             # once) plus the per-record constants and difference lists (read once; ~1e-3 of the writes)
             nbytes = launch_pairs * 8 + n * 4 * 8 + int(n * max(1.0, L / 1000.0 * 2.2)) * 8
             kernel = "consensus_pair_kernel"
-            r = {"bound": "hbm", "achieved": nbytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "kernel_ms": k_ms,
-                 "algorithmic_bytes_per_launch": nbytes,
-                 "frac_of_measured_copy_rate": nbytes / (k_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
-                 "note": "algorithmic bytes = 8 B of result per pair written once + per-record constants and difference "
-                         "lists read once (DESIGN.md 3); the kernel's floor is the HBM write of the N^2/2 results"}
+            hbm = {"bound": "hbm", "achieved": nbytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "kernel_ms": k_ms,
+                   "algorithmic_bytes_per_launch": nbytes,
+                   "frac_of_measured_copy_rate": nbytes / (k_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                   "note": "algorithmic bytes = 8 B of result per pair written once + per-record constants and difference "
+                           "lists read once (DESIGN.md 3); the kernel's floor is the HBM write of the N^2/2 results"}
+            # the f64 finalisation fused into the output phase (reference operation order): f64 VALU instructions per
+            # pair counted in the kernel's ISA (build/asm) against 256 CU x 4 SIMD x 16 f64 lanes x 2.4 GHz
+            f64_ops = F64_OPS_PER_PAIR.get(m, 0)
+            f64_rate = launch_pairs * f64_ops / (k_ms * 1e-3)
+            valu = {"bound": "valu", "achieved": f64_rate / 1e12, "peak": F64_PEAK_LANE_OPS / 1e12, "unit": "T f64-lane-op/s",
+                    "frac": f64_rate / F64_PEAK_LANE_OPS, "kernel": kernel, "kernel_ms": k_ms, "f64_ops_per_pair": f64_ops,
+                    "note": "f64 finalisation instructions per pair (divisions expanded, table-driven log) x pairs against the "
+                            "f64 vector peak (78.6 TFLOP/s = 39.3e12 fma lanes/s); measured issue cost of one f64 op: "
+                            "profiles/r02/ubench_f64_rate.txt"}
+            if valu["frac"] > hbm["frac"]:
+                r = valu
+                r["hbm"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
+            else:
+                r = hbm
+                r["valu_f64"] = {k: valu[k] for k in ("achieved", "peak", "unit", "frac", "f64_ops_per_pair")}
         tr = measured_traffic(args.workload if stock and m == measure else ("C3" if stock and args.workload == "C3raw" and m == "tn93" else ""), kernel)
         r["traffic"] = tr["hbm_bytes_per_launch"] if tr and world == 1 else None
         r["traffic_source"] = (tr["source"] + " — replayed from profiles/, not measured in this run") if tr and world == 1 else None
