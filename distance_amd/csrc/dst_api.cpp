@@ -2,6 +2,7 @@
 // run.  One context = one GPU = one owner thread.  No CPU fallback: every entry point that needs
 // the device fails with DST_ERR_HIP when HIP does.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -47,11 +48,15 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.stats, s.rec.off, s.rec.ent,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent,
                     s.site.cnt, s.site.off, s.site.tab, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
+    if (s.hot) {
+        free_set(*s.hot);
+        delete s.hot;
+    }
     const uint64_t epoch = s.epoch;
     s = DeviceSet{};
     s.epoch = epoch + 1;  // lists other sets hold against this set's reference are stale from now on
@@ -249,34 +254,64 @@ int ensure_lut(dst_ctx *ctx)
     return DST_OK;
 }
 
-// the reference sequence of `s` (plurality code per site over a sample of its records)
+// the reference sequence of `s` (plurality code per site over a sample of its records), its hot sites and the
+// statistics the path choice reads
 int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
     if (s.ref.valid)
         return DST_OK;
     if (s.ref.nchunks != s.nchunks || !s.ref.planes) {
-        for (void *b : {(void *)s.ref.planes, (void *)s.ref.stats})
+        for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats})
             if (b)
                 HIP_TRY(ctx, hipFree(b));
         s.ref.planes = nullptr;
+        s.ref.hot_planes = nullptr;
+        s.ref.hot_sites = nullptr;
         s.ref.stats = nullptr;
         HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 4 * sizeof(uint64_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_planes, s.nchunks * sizeof(uint4)));
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_sites, s.nchunks * kChunkSites * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 8 * sizeof(uint64_t)));
         s.ref.nchunks = s.nchunks;
     }
-    HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 4 * sizeof(uint64_t), stream));
+    HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 8 * sizeof(uint64_t), stream));
     HIP_TRY(ctx, launch_ref_sample(s, stream));
-    HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, launch_hot_list(s, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     s.ref.valid = true;
     return DST_OK;
 }
 
+// hybrid path: the hot columns of `s` (hot by refset's reference) as a packed set of their own
+int ensure_hot(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, hipStream_t stream)
+{
+    const size_t n_hot = refset.ref.h_stats[4];
+    if (s.hot && s.hot->loaded && s.hot_epoch == s.epoch && s.hot_ref_owner == &refset && s.hot_ref_epoch == refset.epoch)
+        return DST_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());  // a run on another stream may still read the old columns
+    if (!s.hot)
+        s.hot = new (std::nothrow) DeviceSet;
+    if (!s.hot)
+        return DST_ERR_NOMEM;
+    int rc = shape_set(ctx, *s.hot, s.n, n_hot);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, launch_compact(s, refset.ref.hot_sites, (uint32_t)n_hot, *s.hot, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    s.hot->loaded = true;
+    s.hot_epoch = s.epoch;
+    s.hot_ref_owner = &refset;
+    s.hot_ref_epoch = refset.epoch;
+    return DST_OK;
+}
+
 // Difference lists of `s` against the reference of `refset` (and, for a column set, the same entries by
 // site and panel).  DST_ERR_CAPACITY: more entries than 32-bit offsets hold — the caller runs dense.
-int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites, hipStream_t stream)
+int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites, bool without_hot, hipStream_t stream)
 {
-    const bool lists_ok = s.rec.valid && s.rec.ref_owner == &refset && s.rec.ref_epoch == refset.epoch;
+    const bool lists_ok = s.rec.valid && s.rec.ref_owner == &refset && s.rec.ref_epoch == refset.epoch &&
+                          s.rec.without_hot == without_hot;
     if (lists_ok && (!want_sites || s.site.valid))
         return DST_OK;
     // other streams may still be reading the buffers about to be rebuilt
@@ -303,7 +338,8 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (want_sites)
         HIP_TRY(ctx, hipMemsetAsync(s.site.cnt, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, false, want_sites, false, s.rec.off, nullptr, s.site.cnt, nullptr,
+    const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, want_sites, false, s.rec.off, nullptr, s.site.cnt, nullptr,
                               nullptr, n_panels, ctx->d_total, stream));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
@@ -325,13 +361,14 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->site_cur, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
     }
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
                               ctx->site_cur, s.site.ent, n_panels, ctx->d_total, stream));
     // complete before the lists are published: later runs may be queued on other streams
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     s.rec.valid = true;
     s.rec.ref_owner = &refset;
     s.rec.ref_epoch = refset.epoch;
+    s.rec.without_hot = without_hot;
     s.aconst_family = -1;
     if (want_sites) {
         s.site.valid = true;
@@ -360,29 +397,45 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
     return DST_OK;
 }
 
-// Which path is cheaper for this launch?  The sampled reference gives, per site, the fraction p_s of records
-// that deviate from it: a pair costs the dense path L sites whatever the data, and the consensus path one
-// output plus about sum_s p_s^2 intersection events.  Constants: measured on MI355X, seconds
-// (tools/calibrate.py, profiles/r02/consensus_calibration.txt): dense site-pairs per second per measure, the
-// consensus path's time per pair with no events (output-bound: n / n_high / raw; finalisation-bound: the
-// others), time per event, and the list build.
-bool consensus_is_cheaper(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles)
+// Which path is cheapest for this launch?  The sampled reference gives, per site, the fraction p_s of records that
+// deviate from it: a pair costs the dense path L sites whatever the data; the consensus path one output plus about
+// sum_s p_s^2 intersection events; the hybrid path the dense cost of the H hot sites (p_s > 3.3 %), one round trip of
+// their tallies through HBM, and the events of the cold sites only.  Constants: measured on MI355X, seconds
+// (tools/calibrate.py, profiles/r02/consensus_calibration.txt).
+int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles)
 {
     //                                            n       n_high  raw      jc69     k80      tn93
     static const double dense_site_pairs_per_s[6] = {2.9e14, 2.9e14, 1.95e14, 1.92e14, 1.82e14, 1.48e14};
     static const double out_s_per_pair[6] = {2.2e-12, 2.2e-12, 2.3e-12, 3.9e-12, 5.0e-12, 1.55e-11};
     constexpr double event_s = 4.5e-12;
-    const double S = (double)std::max<uint64_t>(cols.ref.h_stats[3], 1);
+    const uint64_t *st = cols.ref.h_stats;
+    const double S = (double)std::max<uint64_t>(st[3], 1);
+    const double n_hot = (double)st[4];
     // the sample's sum of squared deviant counts over-states sum p^2 by about (mean list length) / S
-    const double mean_list = (double)cols.ref.h_stats[1] / S;  // differences per record
-    const double events_per_pair = (double)cols.ref.h_stats[2] / (S * S);
+    const double mean_list = (double)st[1] / S, mean_list_cold = (double)st[6] / S;  // differences per record
+    const double events = (double)st[2] / (S * S), events_cold = (double)st[7] / (S * S);
     const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[measure];
     // building the lists reads four bit-planes twice; walking a row's list costs one bucket lookup per panel
-    const double build = (rows.rec.valid && cols.site.valid) ? 0.0
-                                                              : (double)(rows.n + cols.n) * (double)cols.len * 0.5e-12 + 1.5e-4;
-    const double walk = (double)ntiles * kConsensusRowsPerTile * mean_list * 1e-9 / 256.0;
-    const double cons = (double)pairs * (out_s_per_pair[measure] + events_per_pair * event_s) + build + walk + 3e-5;
-    return cons < dense;
+    const bool have_lists = rows.rec.valid && cols.site.valid;
+    const double build = (double)(rows.n + cols.n) * (double)cols.len * 0.5e-12 + 1.5e-4;
+    const double walk = (double)ntiles * kConsensusRowsPerTile * 1e-9 / 256.0;
+    const double cons = (double)pairs * (out_s_per_pair[measure] + events * event_s) +
+                        ((have_lists && !rows.rec.without_hot) ? 0.0 : build) + walk * mean_list + 3e-5;
+    double best = std::min(dense, cons);
+    int path = cons < dense ? DST_PATH_CONSENSUS : DST_PATH_DENSE;
+    if (n_hot > 0 && n_hot * 4 < (double)cols.len) {
+        // hot columns: dense kernels over ceil(H/128) chunks (at least the epilogue: one tally per pair written, then read
+        // by the consensus kernel: ~8 bytes per pair at ~4 TB/s), plus gathering the columns (8 plane bits per record and site)
+        const double hot_dense = (double)pairs * (std::ceil(n_hot / 128.0) * 128.0 / dense_site_pairs_per_s[measure] + 2.2e-12);
+        const double gather = (double)(rows.n + cols.n) * n_hot * 2.5e-11 + 1e-4;
+        const double hybrid = (double)pairs * (out_s_per_pair[measure] + events_cold * event_s) + hot_dense + gather +
+                              ((have_lists && rows.rec.without_hot) ? 0.0 : build) + walk * mean_list_cold + 6e-5;
+        if (hybrid < best) {
+            best = hybrid;
+            path = DST_PATH_HYBRID;
+        }
+    }
+    return path;
 }
 
 int run_common(dst_ctx *ctx, int measure, bool square, int row_slot, int col_slot, uint64_t rb,
@@ -435,9 +488,10 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         if (rc)
             return rc;
     }
-    // ---- path: consensus-delta (work ~ differences from a reference sequence) or dense bit-planes (work ~ L)
+    // ---- path: dense bit-planes (work ~ L), consensus-delta (work ~ differences from a reference sequence), or the
+    // hybrid of the two (hot columns dense, the rest by lists)
     int rc = DST_OK;
-    bool use_consensus = false;
+    int path = DST_PATH_DENSE;
     if (ctx->path != DST_PATH_DENSE && consensus_shape_ok(rows, cols)) {
         rc = ensure_lut(ctx);
         if (!rc)
@@ -446,21 +500,26 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             return rc;
         const uint64_t n_panels = (cols.n + kPanelCols - 1) / kPanelCols;
         const uint64_t tiles_est = std::max<uint64_t>(1, n_panels * ((re - rb + kConsensusRowsPerTile - 1) / kConsensusRowsPerTile) / (square ? 2 : 1));
-        use_consensus = ctx->path == DST_PATH_CONSENSUS ||
-                        consensus_is_cheaper(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu));
-        if (use_consensus) {
-            rc = ensure_index(ctx, cols, cols, true, stream);
+        path = ctx->path != DST_PATH_AUTO ? ctx->path
+                                          : cheapest_path(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu));
+        const uint64_t n_hot = cols.ref.h_stats[4];
+        if (path == DST_PATH_HYBRID && (n_hot == 0 || n_hot * 2 > cols.len))
+            path = n_hot == 0 ? DST_PATH_CONSENSUS : DST_PATH_DENSE;  // nothing hot / mostly hot: the plain paths
+        if (path != DST_PATH_DENSE) {
+            const bool without_hot = path == DST_PATH_HYBRID;
+            rc = ensure_index(ctx, cols, cols, true, without_hot, stream);
             if (!rc && &rows != &cols)
-                rc = ensure_index(ctx, rows, cols, false, stream);
+                rc = ensure_index(ctx, rows, cols, false, without_hot, stream);
             if (rc == DST_ERR_CAPACITY)
-                use_consensus = false;  // denser than the lists can index: the dense path handles any input
+                path = DST_PATH_DENSE;  // denser than the lists can index: the dense path handles any input
             else if (rc)
                 return rc;
         }
     }
-    if (use_consensus) {
+    if (path != DST_PATH_DENSE) {
         const int fam = family_of(measure);
         const bool wide = rows.len >= 65536;
+        const bool hybrid = path == DST_PATH_HYBRID;
         rc = ensure_aconst(ctx, cols, cols, fam, wide, stream);
         if (!rc && &rows != &cols)
             rc = ensure_aconst(ctx, rows, cols, fam, wide, stream);
@@ -470,12 +529,53 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             rc = prepare_schedule(ctx, square, rb, re, cols.n, (int)kConsensusRowsPerTile, -1, stream, &d_tiles, &ntiles);
         if (rc)
             return rc;
-        // F_k: every site where the reference is a known base adds f_k(base, base)
+        const void *d_hot = nullptr;
+        if (hybrid && ntiles) {
+            // the hot columns through the dense kernels: their tallies, in canonical order, into a scratch buffer
+            rc = ensure_hot(ctx, cols, cols, stream);
+            if (!rc && &rows != &cols)
+                rc = ensure_hot(ctx, rows, cols, stream);
+            const int hot_kind = wide ? DST_OUT_TALLY : DST_OUT_TALLY16;
+            const size_t hot_bytes = dst_out_bytes(measure, hot_kind, total_pairs);
+            if (!rc && ctx->hot_tally_bytes < hot_bytes) {
+                HIP_TRY(ctx, hipDeviceSynchronize());
+                rc = ensure_bytes(ctx, &ctx->hot_tally, &ctx->hot_tally_bytes, hot_bytes);
+            }
+            if (rc)
+                return rc;
+            DeviceSet &hrows = *rows.hot, &hcols = *cols.hot;
+            const TileShape hts = tile_shape(measure, ctx->variant);
+            uint32_t hblocks = 0;
+            const BlockDesc *d_hblocks = nullptr;
+            rc = prepare_blocks(ctx, square, rb, re, cols.n, hts, stream, &d_hblocks, &hblocks);
+            if (rc)
+                return rc;
+            PairLaunch hp{};
+            hp.rows = &hrows;
+            hp.cols = &hcols;
+            hp.square = square;
+            hp.row_begin = rb;
+            hp.row_end = re;
+            hp.out_base = square ? square_row_start(cols.n, rb) : 0;
+            hp.out_kind = hot_kind;
+            hp.d_out = ctx->hot_tally;
+            hp.d_blocks = d_hblocks;
+            hp.nblocks = hblocks;
+            hp.ksplit = 1;
+            // one scratch buffer per context: a hybrid run on another stream must be done reading it first
+            if (ctx->hot_used)
+                HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->hot_free, 0));
+            if (hblocks)
+                HIP_TRY(ctx, launch_pairs(measure, ctx->variant, hp, stream));
+            d_hot = ctx->hot_tally;
+        }
+        // F_k: every (cold) site where the reference is a known base adds f_k(base, base)
         int unit[4];
         site_tallies(measure, 136, 136, unit);
+        const uint64_t n_known = cols.ref.h_stats[0] - (hybrid ? cols.ref.h_stats[5] : 0);
         int64_t f[4];
         for (int k = 0; k < 4; ++k)
-            f[k] = (int64_t)unit[k] * (int64_t)cols.ref.h_stats[0];
+            f[k] = (int64_t)unit[k] * (int64_t)n_known;
         uint32_t f_words[kMaxWords];
         pack_tallies(fam, wide, f, f_words);
         ConsensusLaunch cl{};
@@ -491,12 +591,17 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         cl.ntiles = ntiles;
         cl.wide = wide;
         cl.d_lut = ctx->d_lut;
-        ctx->last_path = DST_PATH_CONSENSUS;
+        cl.d_hot = d_hot;
+        ctx->last_path = path;
         if (ntiles) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
             HIP_TRY(ctx, launch_consensus_pairs(measure, cl, f_words, stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
             ctx->timed_pair = true;
+            if (d_hot) {
+                HIP_TRY(ctx, hipEventRecord(ctx->hot_free, stream));
+                ctx->hot_used = true;
+            }
         }
         if (!stream_v)
             HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -662,6 +767,8 @@ int dst_create(int device, dst_ctx **out)
         return bail(c, e, "hipMalloc");
     if ((e = hipEventCreateWithFlags(&c->scratch_free, hipEventDisableTiming)) != hipSuccess)
         return bail(c, e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->hot_free, hipEventDisableTiming)) != hipSuccess)
+        return bail(c, e, "hipEventCreate");
     *out = c;
     return DST_OK;
 }
@@ -679,13 +786,15 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
-    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur, ctx->host_out})
+    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur, ctx->host_out, ctx->hot_tally})
         if (b)
             (void)hipFree(b);
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
     if (ctx->scratch_free)
         (void)hipEventDestroy(ctx->scratch_free);
+    if (ctx->hot_free)
+        (void)hipEventDestroy(ctx->hot_free);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
     for (auto &ev : ctx->ev)
@@ -709,7 +818,7 @@ int dst_set_ksplit(dst_ctx *ctx, int ksplit)
 
 int dst_set_path(dst_ctx *ctx, int path)
 {
-    if (!ctx || path < DST_PATH_AUTO || path > DST_PATH_CONSENSUS)
+    if (!ctx || path < DST_PATH_AUTO || path > DST_PATH_HYBRID)
         return DST_ERR_ARG;
     ctx->path = path;
     return DST_OK;
@@ -905,7 +1014,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e == hipSuccess)
         e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
@@ -933,7 +1042,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
         return done(DST_OK);
     e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, 1, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

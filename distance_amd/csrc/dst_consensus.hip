@@ -52,6 +52,7 @@ __device__ __forceinline__ uint32_t popc4(uint4 v)
 __global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restrict__ planes32, uint32_t n,
                                                          uint32_t len, uint32_t nchunks, uint32_t npad,
                                                          uint32_t samples, uint4 *__restrict__ ref_planes,
+                                                         uint4 *__restrict__ hot_planes,
                                                          unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t part[4][5][128];
@@ -97,22 +98,119 @@ __global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restr
         if ((b & 63) == 0)
             reinterpret_cast<unsigned long long *>(&ref_planes[(size_t)p * nchunks + c])[wave] = m;
     }
+    // "hot" sites: more than kHotPermille of the sampled records deviate from the plurality (clade-defining
+    // mutations, indel-rich columns).  Their events grow with p^2; the hybrid path gives these columns to the
+    // dense kernels instead (dst_api.cpp) and keeps them out of the lists.
+    const uint32_t devs = real ? samples - best : 0u;
+    const bool hot = devs * 1000u > samples * kHotPermille;
+    const unsigned long long hot_mask = __ballot(hot);
+    if ((b & 63) == 0)
+        reinterpret_cast<unsigned long long *>(&hot_planes[c])[wave] = hot_mask;
     // statistics for the path choice: known reference sites, sum and sum of squares of the sampled
-    // records that deviate from the plurality class
+    // records that deviate from the plurality class — over all sites and over the cold ones alone
     const unsigned long long known = __ballot(real && cls < 4);
-    uint32_t dev = real ? samples - best : 0u, dev2 = dev * dev;
+    const unsigned long long known_hot = __ballot(real && cls < 4 && hot);
+    uint32_t dev = devs, dev2 = devs * devs, cdev = hot ? 0u : devs, cdev2 = hot ? 0u : devs * devs;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         dev += __shfl_xor(dev, o);
         dev2 += __shfl_xor(dev2, o);
+        cdev += __shfl_xor(cdev, o);
+        cdev2 += __shfl_xor(cdev2, o);
     }
     if ((b & 63) == 0) {
         atomicAdd(&stats[0], (unsigned long long)__builtin_popcountll(known));
         atomicAdd(&stats[1], (unsigned long long)dev);
         atomicAdd(&stats[2], (unsigned long long)dev2);
+        atomicAdd(&stats[4], (unsigned long long)__builtin_popcountll(hot_mask));
+        atomicAdd(&stats[5], (unsigned long long)__builtin_popcountll(known_hot));
+        atomicAdd(&stats[6], (unsigned long long)cdev);
+        atomicAdd(&stats[7], (unsigned long long)cdev2);
     }
     if (c == 0 && b == 0)
         stats[3] = samples;
+}
+
+// ascending list of the hot sites (one block; nchunks is at most a few ten thousand)
+__global__ __launch_bounds__(1024) void hot_list_kernel(const uint4 *__restrict__ hot_planes, uint32_t nchunks,
+                                                        uint32_t *__restrict__ hot_sites)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t base;
+    if (threadIdx.x == 0)
+        base = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 1024) {
+        const uint32_t c = c0 + threadIdx.x;
+        const uint4 m = c < nchunks ? hot_planes[c] : make_uint4(0, 0, 0, 0);
+        const uint32_t pc = popc4(m);
+        uint32_t incl = pc, up;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            up = __shfl_up(incl, o);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
+        }
+        if ((threadIdx.x & 63u) == 63u)
+            wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t off = base, total = 0;
+        for (uint32_t wv = 0; wv < 16; ++wv) {
+            if (wv < (threadIdx.x >> 6)) off += wave_tot[wv];
+            total += wave_tot[wv];
+        }
+        uint32_t at = off + incl - pc;
+        const uint32_t w4[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t bits = w4[w];
+            while (bits) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1;
+                hot_sites[at++] = c * kChunkSites + 32u * w + bit;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            base += total;
+        __syncthreads();
+    }
+}
+
+// The hot columns of a set as a packed set of their own (all 8 planes): one thread = one (record, chunk of 128
+// hot sites); lanes run along records like pack_kernel's, the site list is wave-uniform.
+__global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict__ planes32, uint32_t n, uint32_t nchunks,
+                                                      uint32_t npad, const uint32_t *__restrict__ hot_sites, uint32_t n_hot,
+                                                      uint32_t hot_chunks, uint32_t hot_npad, uint4 *__restrict__ out)
+{
+    const uint32_t r = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t hc = blockIdx.x;
+    if (r >= hot_npad)
+        return;
+    uint32_t o[PL_COUNT][4];
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            o[p][w] = (p <= PL_T) ? 0xFFFFFFFFu : 0u;  // all N
+    if (r < n) {
+        const size_t ps = (size_t)nchunks * npad * 4;
+        for (uint32_t k = 0; k < kChunkSites; ++k) {
+            const uint32_t idx = hc * kChunkSites + k;
+            if (idx >= n_hot)
+                break;
+            const uint32_t s = hot_sites[idx];
+            const size_t at = ((size_t)(s >> 7) * npad + r) * 4 + ((s >> 5) & 3u);
+            const uint32_t bit = s & 31u, ow = k >> 5, ob = k & 31u;
+#pragma unroll
+            for (int p = 0; p < PL_COUNT; ++p) {
+                const uint32_t v = (planes32[p * ps + at] >> bit) & 1u;
+                o[p][ow] = (o[p][ow] & ~(1u << ob)) | (v << ob);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+        out[((size_t)p * hot_chunks + hc) * hot_npad + r] = make_uint4(o[p][0], o[p][1], o[p][2], o[p][3]);
 }
 
 // =============================================================================================
@@ -126,7 +224,8 @@ __global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restr
 // FILL == true : rec = scanned offsets, site = scanned bucket offsets, site_cur = zeroed cursors.
 template <bool FILL>
 __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ planes,
-                                                    const uint4 *__restrict__ ref_planes, uint32_t n,
+                                                    const uint4 *__restrict__ ref_planes,
+                                                    const uint4 *__restrict__ hot_planes, uint32_t n,
                                                     uint32_t nchunks, uint32_t npad, int want_sites,
                                                     int skip_nclass, uint32_t *__restrict__ rec,
                                                     uint32_t *__restrict__ rec_ent, uint32_t *__restrict__ site,
@@ -159,6 +258,13 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
             d.y = (A.y ^ rA.y) | (G.y ^ rG.y) | (C.y ^ rC.y) | (T.y ^ rT.y);
             d.z = (A.z ^ rA.z) | (G.z ^ rG.z) | (C.z ^ rC.z) | (T.z ^ rT.z);
             d.w = (A.w ^ rA.w) | (G.w ^ rG.w) | (C.w ^ rC.w) | (T.w ^ rT.w);
+            if (hot_planes) {  // hybrid path: the hot columns belong to the dense kernels
+                const uint4 h = hot_planes[c];
+                d.x &= ~h.x;
+                d.y &= ~h.y;
+                d.z &= ~h.z;
+                d.w &= ~h.w;
+            }
             if (skip_nclass) {  // get_differences(): seq[i] < 240 (src/fastaio.rs:70)
                 d.x &= ~(A.x & G.x & C.x & T.x);
                 d.y &= ~(A.y & G.y & C.y & T.y);
@@ -326,6 +432,28 @@ template <int FAM, bool WIDE>
 struct Pack {
     static constexpr int NT = FAM == FAM_NHIGH ? 1 : FAM == FAM_RAW ? 2 : FAM == FAM_K80 ? 3 : 4;
     static constexpr int W = WIDE ? NT : (NT + 1) / 2;
+    // tallies of the hot columns, written by the dense kernels as DST_OUT_TALLY16 (narrow) / DST_OUT_TALLY (wide):
+    // the 16-bit layout of 2 and 4 tallies IS the packed accumulator word
+    static __device__ __forceinline__ void add_hot(uint32_t *t, const void *hot, uint64_t at)
+    {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                t[k] += static_cast<const uint32_t *>(hot)[at * NT + k];
+        } else if constexpr (NT == 1) {
+            t[0] += static_cast<const uint16_t *>(hot)[at];
+        } else if constexpr (NT == 2) {
+            t[0] += static_cast<const uint32_t *>(hot)[at];
+        } else if constexpr (NT == 3) {
+            const uint16_t *p = static_cast<const uint16_t *>(hot) + at * 3;
+            t[0] += (uint32_t)p[0] | (uint32_t)p[1] << 16;
+            t[1] += p[2];
+        } else {
+            const uint2 v = static_cast<const uint2 *>(hot)[at];
+            t[0] += v.x;
+            t[1] += v.y;
+        }
+    }
     static __device__ __forceinline__ void unpack(const uint32_t *t, uint32_t *o)
     {
         if constexpr (WIDE || NT == 1) {
@@ -378,7 +506,8 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
     const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
     uint32_t n_sites, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
-    const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square)
+    const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square,
+    const void *__restrict__ hot)
 {
     using P = Pack<FAM, WIDE>;
     constexpr int W = P::W, NT = P::NT;
@@ -586,6 +715,8 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
                                 cav = k + h < pcols ? col_a[(size_t)w * col_npad + t + h] : 0u;
                             tot[w] = a + cav + aq[w];
                         }
+                        if (hot && live[h])
+                            P::add_hot(tot, hot, row_at + t + h);   // hybrid path: the dense kernels' tallies of the hot columns
                         P::unpack(tot, o[h]);
                     }
                     const uint64_t at = row_at + t;
@@ -705,22 +836,39 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, 512);
     hipLaunchKernelGGL(ref_sample_kernel, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), (uint32_t)set.n, (uint32_t)set.len,
-                       (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes, set.ref.hot_planes,
                        reinterpret_cast<unsigned long long *>(set.ref.stats));
     return hipGetLastError();
 }
 
-hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, bool fill, bool want_sites, bool skip_nclass,
+hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hot_list_kernel, dim3(1), dim3(1024), 0, stream, set.ref.hot_planes, (uint32_t)set.nchunks,
+                       set.ref.hot_sites);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint32_t n_hot, DeviceSet &dst, hipStream_t stream)
+{
+    dim3 grid((unsigned)dst.nchunks, (unsigned)((dst.npad + 255) / 256));
+    hipLaunchKernelGGL(compact_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(src.planes),
+                       (uint32_t)src.n, (uint32_t)src.nchunks, (uint32_t)src.npad, hot_sites, n_hot, (uint32_t)dst.nchunks,
+                       (uint32_t)dst.npad, dst.planes);
+    return hipGetLastError();
+}
+
+hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
+                        bool skip_nclass,
                         uint32_t *rec, uint32_t *rec_ent, uint32_t *site, uint32_t *site_cur, uint32_t *site_ent,
                         uint32_t n_panels, unsigned long long *total, hipStream_t stream)
 {
     const unsigned blocks = (unsigned)((set.n + 31) / 32);
     if (fill)
-        hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes,
+        hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
                            skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, n_panels, total);
     else
-        hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes,
+        hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
                            skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, n_panels, total);
     return hipGetLastError();
@@ -792,7 +940,7 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
                        cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.tab, cl.cols->site.ent,
                        cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
-                       (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0);
+                       (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0, cl.d_hot);
     return hipGetLastError();
 }
 

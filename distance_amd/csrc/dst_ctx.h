@@ -39,6 +39,10 @@ struct dst_ctx {
     size_t scan_tmp_bytes = 0;
     uint32_t *site_cur = nullptr;
     size_t site_cur_bytes = 0;
+    void *hot_tally = nullptr;  // hybrid path: the dense kernels' tallies of the hot columns (grow-only)
+    size_t hot_tally_bytes = 0;
+    hipEvent_t hot_free = nullptr;  // recorded after the last reader of `hot_tally`
+    bool hot_used = false;
     void *host_out = nullptr;  // device staging of the *_host run forms (grow-only)
     size_t host_out_bytes = 0;
     int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced

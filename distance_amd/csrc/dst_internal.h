@@ -54,11 +54,16 @@ constexpr uint32_t kSiteBits = 25;         // record-list entries: site | refere
 constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
+constexpr uint32_t kHotPermille = 33;      // hybrid path: a site is "hot" when more than 3.3 % of the sampled records deviate
 
 struct ConsensusRef {             // the reference sequence, sampled from the set that owns it
     uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records'); N past len
-    uint64_t *stats = nullptr;    // device: {known sites, sum of deviants, sum of deviants^2, sample size}
-    uint64_t h_stats[4] = {0, 0, 0, 0};
+    uint4 *hot_planes = nullptr;  // [nchunks] bit = 1: a hot site (kHotPermille), handed to the dense kernels by the hybrid path
+    uint32_t *hot_sites = nullptr;  // [n_hot] the hot sites, ascending
+    // device: {known sites, sum of deviants, sum of deviants^2, sample size, hot sites, known hot sites,
+    //          sum of deviants over the cold sites, sum of deviants^2 over the cold sites}
+    uint64_t *stats = nullptr;
+    uint64_t h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t nchunks = 0;
     bool valid = false;
 };
@@ -70,6 +75,7 @@ struct RecordIndex {              // per record: the sites where it differs from
     uint64_t total = 0;
     const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
     uint64_t ref_epoch = 0;
+    bool without_hot = false;         // hybrid path: the hot sites are left out
     bool valid = false;
 };
 
@@ -101,6 +107,11 @@ struct DeviceSet {
     bool aconst_wide = false;
     uint64_t aconst_epoch = 0, aconst_ref_epoch = 0;
     const void *aconst_ref_owner = nullptr;
+    bool aconst_without_hot = false;
+    // hybrid path: the hot columns of this set (by some set's reference) as a packed set of their own
+    DeviceSet *hot = nullptr;
+    const void *hot_ref_owner = nullptr;
+    uint64_t hot_epoch = 0, hot_ref_epoch = 0;
 };
 
 struct BlockDesc {
@@ -162,13 +173,18 @@ struct ConsensusLaunch {
     uint32_t ntiles;
     bool wide;                   // one 32-bit word per tally (alignments of 65,536 sites or more)
     const ConsensusLut *d_lut;
+    const void *d_hot = nullptr; // hybrid path: the dense kernels' tallies of the hot columns (TALLY16 / TALLY layout)
 };
 
 // ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
 // count pass (fill == false): rec_cnt[n], site_cnt[len * n_panels] (when want_sites), *total
 // fill pass: entries behind the scanned offsets.  ref_planes: [4][nchunks] uint4.
-hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, bool fill, bool want_sites, bool skip_nclass,
+hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
+hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint32_t n_hot, DeviceSet &dst, hipStream_t stream);
+// hot_planes != NULL: sites whose bit is set are left out of the lists
+hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
+                        bool skip_nclass,
                         uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_off_or_cnt, uint32_t *site_cur,
                         uint32_t *site_ent, uint32_t n_panels, unsigned long long *total, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words

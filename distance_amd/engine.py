@@ -17,7 +17,7 @@ MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
 FLOAT_MEASURES = ("raw", "jc69", "k80", "tn93")
 OUT_DISTANCE, OUT_TALLY, OUT_TALLY16 = 0, 1, 2
-PATHS = {"auto": 0, "dense": 1, "consensus": 2}
+PATHS = {"auto": 0, "dense": 1, "consensus": 2, "hybrid": 3}
 
 
 def _measure_id(measure) -> int:
@@ -148,7 +148,7 @@ class Engine:
         self._check(self._lib.dst_set_path(self._h, PATHS[path] if isinstance(path, str) else int(path)))
 
     def last_path(self) -> str:
-        return {1: "dense", 2: "consensus"}.get(self._lib.dst_last_path(self._h), "?")
+        return {1: "dense", 2: "consensus", 3: "hybrid"}.get(self._lib.dst_last_path(self._h), "?")
 
     # ---- per-alignment precompute of -m n (src/lib.rs:223-231) ------------------------------
     def consensus(self, both_slots: bool = False) -> np.ndarray:

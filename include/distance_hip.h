@@ -101,11 +101,15 @@ int dst_set_ksplit(dst_ctx *ctx, int ksplit);
  *                      records share.  Low-diversity alignments (SARS-CoV-2-like) run output-bound.
  *                      Shapes its lists cannot index (zero-width alignments, 2^28 or more records or sites,
  *                      more than 2^31 differences in a set) run dense even when this is selected.
+ *  DST_PATH_HYBRID:    consensus path for the "cold" columns, dense kernels for the hot ones (columns where more than
+ *                      3.3 % of a sample of the records deviate from the plurality: clade-defining mutations), whose
+ *                      tallies the consensus kernel adds in.  Alignments with phylogenetic structure stay fast.
+ *                      Without hot columns it is the consensus path; with mostly hot columns the dense one.
  *  DST_PATH_AUTO:      (default) per launch, whichever a sampled estimate of the alignment's diversity
- *                      says is faster. */
-typedef enum { DST_PATH_AUTO = 0, DST_PATH_DENSE = 1, DST_PATH_CONSENSUS = 2 } dst_path;
+ *                      says is fastest. */
+typedef enum { DST_PATH_AUTO = 0, DST_PATH_DENSE = 1, DST_PATH_CONSENSUS = 2, DST_PATH_HYBRID = 3 } dst_path;
 int dst_set_path(dst_ctx *ctx, int path);
-/* DST_PATH_DENSE or DST_PATH_CONSENSUS: what the most recent run on this context used */
+/* DST_PATH_DENSE, DST_PATH_CONSENSUS or DST_PATH_HYBRID: what the most recent run on this context used */
 int dst_last_path(const dst_ctx *ctx);
 
 /* ---- input: replaces Setup.loaded_fastas[slot] (src/lib.rs:133-144) --------------------- */

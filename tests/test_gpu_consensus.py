@@ -245,3 +245,97 @@ def test_n_equals_the_sparse_walk_of_the_reference(eng):
     dev = eng.differences(0, cons)
     assert all(np.array_equal(dev[r].astype(np.uint64), diffs[r]) for r in range(100))
     eng.set_path("auto")
+
+
+def clade_alignment(n, L, seed, clade_frac=0.35, clade_sites=0.02, subs=2e-3):
+    """Phylogenetic structure: a clade (a third of the records) shares substitutions at 2 % of the sites, a
+    sub-clade a few more, some columns are indel-rich — on top of sparse private differences."""
+    rng = np.random.default_rng(seed)
+    codes = low_diversity(n, L, seed + 1, subs=subs)
+    root = codes[0].copy()
+    clade = rng.random(n) < clade_frac
+    sub = clade & (rng.random(n) < 0.4)
+    sites = np.nonzero(rng.random(L) < clade_sites)[0]
+    sub_sites = np.nonzero(rng.random(L) < clade_sites / 3)[0]
+    alt = {136: 72, 72: 136, 40: 24, 24: 40}
+    for s_ in sites:
+        codes[clade, s_] = alt.get(int(root[s_]), 24)
+    for s_ in sub_sites:
+        codes[sub, s_] = 24 if root[s_] != 24 else 40
+    for s_ in rng.integers(0, L, max(1, L // 200)):          # indel-rich columns: a fifth of the records gapped or N
+        m = rng.random(n) < 0.2
+        codes[m, s_] = rng.choice(np.array([244, 240], np.uint8), size=int(m.sum()))
+    for s_ in rng.integers(0, L, max(1, L // 400)):          # ambiguity codes at a common variant
+        m = rng.random(n) < 0.1
+        codes[m, s_] = rng.choice(CODES[4:14], size=int(m.sum()))
+    return np.ascontiguousarray(codes)
+
+
+def test_hybrid_path_on_clade_structured_alignments(eng):
+    """Hot columns (common variants) through the dense kernels, the rest through the lists: the same integers and
+    the same device distances as either plain path, square / two files / stream order, every measure."""
+    a = clade_alignment(900, 3000, 31)
+    b = clade_alignment(130, 3000, 32)
+    eng.upload(0, a)
+    eng.upload(1, b)
+    for m in ALL:
+        res = {}
+        for path in ("dense", "consensus", "hybrid"):
+            eng.set_path(path)
+            res[path] = (eng.run_square(m, tallies=True), eng.run_square(m), eng.run_rect(m, tallies=True),
+                         eng.run_rect(m, row_slot=1, col_slot=0, row_begin=3, row_end=77))
+            assert eng.last_path() == path, (m, path)
+        for path in ("consensus", "hybrid"):
+            for x, y in zip(res["dense"], res[path]):
+                assert np.array_equal(x, y, equal_nan=True), (m, path)
+        om = "n_high" if m == "n" else m
+        ij = oracle.pairs_square(len(a))
+        for k in range(0, len(ij), 997):
+            i, j = int(ij[k][0]), int(ij[k][1])
+            assert list(res["hybrid"][0][k]) == [int(x) for x in oracle.tallies(om, a[i], a[j])], (m, i, j)
+    eng.set_path("auto")
+
+
+def test_hybrid_wide_tallies_and_row_ranges(eng):
+    L = 66001
+    a = clade_alignment(60, L, 41, clade_sites=0.01)
+    a[7] = a[8]
+    eng.upload(0, a)
+    for m in ("n_high", "raw", "k80", "tn93"):
+        eng.set_path("dense")
+        want = eng.run_square(m, tallies=True)
+        eng.set_path("hybrid")
+        assert np.array_equal(eng.run_square(m, tallies=True), want), m
+        assert eng.last_path() == "hybrid"
+        cat = np.concatenate([eng.run_square(m, rb, re, tallies=True) for rb, re in ((0, 11), (11, 12), (12, 60))])
+        assert np.array_equal(cat, want), m
+    eng.set_path("auto")
+
+
+def test_auto_takes_the_hybrid_for_structured_data(eng):
+    import torch
+    n, L = 16000, 9000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    base = torch.tensor([136, 40, 72, 24], dtype=torch.uint8, device=dev)
+    root = torch.randint(0, 4, (L,), device=dev, generator=g)
+    idx = root.expand(n, L).clone()
+    mut = torch.rand((n, L), device=dev, generator=g) < 1e-3
+    idx[mut] = (idx[mut] + 1) % 4
+    clade = torch.rand(n, device=dev, generator=g) < 0.33
+    sites = torch.rand(L, device=dev, generator=g) < 0.02
+    sel = clade[:, None] & sites[None, :]
+    idx[sel] = (root.expand(n, L)[sel] + 1) % 4
+    codes = base[idx].contiguous()
+    pairs = n * (n - 1) // 2
+    out = {p: torch.empty(pairs, dtype=torch.float64, device=dev) for p in ("auto", "dense")}
+    for p in ("auto", "dense"):
+        eng.set_path(p)
+        eng.upload_device(0, codes.data_ptr(), n, L, L)
+        eng.run_square_device("raw", 0, n, out[p].data_ptr(), pairs * 8)
+        torch.cuda.synchronize()
+        if p == "auto":
+            assert eng.last_path() == "hybrid"
+    assert torch.equal(out["auto"].view(torch.int64), out["dense"].view(torch.int64))      # every bit of every distance
+    eng.set_path("auto")

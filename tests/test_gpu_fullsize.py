@@ -74,7 +74,7 @@ def test_c3_50000_x_30000_raw_and_tn93(eng, c3_codes, path):
         eng.set_path("auto")
 
 
-@pytest.mark.parametrize("path", ["dense", "consensus"])
+@pytest.mark.parametrize("path", ["dense", "consensus", "hybrid"])
 def test_c2_10000_x_30000_raw_whole_triangle(eng, path):
     n, L = 10_000, 30_000
     codes = synth.alignment(synth.SEED ^ 2, n, L)
@@ -82,7 +82,8 @@ def test_c2_10000_x_30000_raw_whole_triangle(eng, path):
     eng.upload(0, codes)
     d = eng.run_square("raw")                        # all 49,995,000 pairs
     tl = eng.run_square("raw", tallies=True)
-    assert d.shape == (n * (n - 1) // 2,) and eng.last_path() == path
+    # (the synthetic star phylogeny has no hot columns: "hybrid" runs as the consensus path there)
+    assert d.shape == (n * (n - 1) // 2,) and eng.last_path() == ("consensus" if path == "hybrid" else path)
     with np.errstate(invalid="ignore", divide="ignore"):
         want = tl[:, 0] / tl[:, 1].astype(np.float64)
     assert np.array_equal(d, want, equal_nan=True)    # IEEE division: device == host on the same tallies

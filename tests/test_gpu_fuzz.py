@@ -58,7 +58,7 @@ def test_randomised_parity_sweep():
                 m = str(m)
                 eng.set_variant(int(rng.integers(0, lib.dst_variant_count(da.MEASURES[m]))))
                 eng.set_ksplit(int(rng.choice([0, 0, 1, 3, 16])))
-                eng.set_path(str(rng.choice(["dense", "consensus", "consensus", "auto"])))
+                eng.set_path(str(rng.choice(["dense", "consensus", "hybrid", "hybrid", "auto"])))
                 om = "n_high" if m == "n" else m
                 if not two:
                     rb = int(rng.integers(0, n))

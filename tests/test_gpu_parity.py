@@ -16,9 +16,10 @@ TOL = 1e-12
 ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
 
 
-@pytest.fixture(scope="module", params=["dense", "consensus"])
+@pytest.fixture(scope="module", params=["dense", "consensus", "hybrid"])
 def eng(request):
-    """Every parity test runs on both kernel families: the dense bit-plane tiles and the consensus-delta path."""
+    """Every parity test runs on every kernel path: the dense bit-plane tiles, the consensus-delta lists, and the
+    hybrid of the two (hot columns dense, the rest by lists; it falls back to a plain path where there is nothing to split)."""
     e = da.Engine(0)
     e.set_path(request.param)
     e.path_name = request.param
