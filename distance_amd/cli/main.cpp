@@ -435,19 +435,95 @@ struct Ctx {
 };
 
 // One slab of results: rows [rb, re) of the row set against the column set (square: j > i).
+// Text buffers come from a pool: a fresh multi-megabyte allocation is mmap'ed and page-faulted in on every slab
+// (the kernel zeroes each page), which cost a fifth of the formatting time at 1e9 lines.
+class TextPool {
+public:
+    ~TextPool()
+    {
+        for (auto &b : free_)
+            delete[] b.first;
+    }
+    char *acquire(size_t need, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            size_t best = free_.size();
+            for (size_t k = 0; k < free_.size(); ++k)
+                if (free_[k].second >= need && (best == free_.size() || free_[k].second < free_[best].second))
+                    best = k;
+            if (best != free_.size()) {
+                auto b = free_[best];
+                free_.erase(free_.begin() + (long)best);
+                *cap = b.second;
+                return b.first;
+            }
+        }
+        *cap = need;
+        return new char[need];
+    }
+    void release(char *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (free_.size() >= 64) {  // bound what is kept
+            delete[] p;
+            return;
+        }
+        free_.emplace_back(p, cap);
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::pair<char *, size_t>> free_;
+};
+TextPool g_text_pool;
+
 // un-initialised growable char buffer (std::string::resize would zero-fill every byte first)
 struct TextBuf {
-    std::unique_ptr<char[]> p;
+    struct Ptr {  // minimal owner so that the call sites keep reading `out.p.get()`
+        char *raw = nullptr;
+        char *get() const { return raw; }
+    } p;
     size_t len = 0, cap = 0;
+    TextBuf() = default;
+    TextBuf(const TextBuf &) = delete;
+    TextBuf &operator=(const TextBuf &) = delete;
+    TextBuf(TextBuf &&o) noexcept : p(o.p), len(o.len), cap(o.cap)
+    {
+        o.p.raw = nullptr;
+        o.len = o.cap = 0;
+    }
+    TextBuf &operator=(TextBuf &&o) noexcept
+    {
+        if (this != &o) {
+            drop();
+            p = o.p;
+            len = o.len;
+            cap = o.cap;
+            o.p.raw = nullptr;
+            o.len = o.cap = 0;
+        }
+        return *this;
+    }
+    ~TextBuf() { drop(); }
+    void drop()
+    {
+        if (p.raw)
+            g_text_pool.release(p.raw, cap);
+        p.raw = nullptr;
+        len = cap = 0;
+    }
     void ensure(size_t need)
     {
         if (len + need <= cap)
             return;
-        const size_t ncap = std::max(cap + cap / 2, len + need + ((size_t)1 << 16));
-        std::unique_ptr<char[]> q(new char[ncap]);
+        size_t ncap = 0;
+        char *q = g_text_pool.acquire(std::max(cap + cap / 2, len + need + ((size_t)1 << 16)), &ncap);
         if (len)
-            std::memcpy(q.get(), p.get(), len);
-        p = std::move(q);
+            std::memcpy(q, p.raw, len);
+        if (p.raw)
+            g_text_pool.release(p.raw, cap);
+        p.raw = q;
         cap = ncap;
     }
 };
@@ -544,10 +620,25 @@ void format_slab(const Job &job, Slab &slab)
     size_t id_max = 0;
     for (const auto &id : job.cols->ids)
         id_max = std::max(id_max, id.size());
+    // raw / jc69 / k80: the distance is a function of the pair's tallies alone, and the same tallies recur all the
+    // time (a few hundred distinct (n, d) in a SARS-CoV-2-like alignment): a small direct-mapped memo of
+    // tallies -> printed number takes most pairs past dst_finalize and the exact decimal conversion.  A miss
+    // computes it the ordinary way, so the text is the same either way.
+    const bool memo_ok = job.measure == DST_RAW || job.measure == DST_JC69 || job.measure == DST_K80;
+    struct Memo {
+        uint64_t key_lo;
+        uint32_t key_hi;
+        uint8_t len;   // 0: empty
+        char text[27];
+    };
+    constexpr size_t kMemoSize = 1u << 14;
     auto work = [&](size_t k) {
         TextBuf &out = slab.text[k];
+        std::vector<Memo> memo(memo_ok ? kMemoSize : 0);
+        for (auto &mslot : memo)
+            mslot.len = 0;
         // first guess: 16 characters of number per line; grows (rarely) if a line needs more
-        out.ensure((size_t)pairs_between(cut[k], cut[k + 1]) * (id_max + 20) + 64);
+        out.ensure((size_t)pairs_between(cut[k], cut[k + 1]) * (2 * id_max + 20) + 64);
         for (uint64_t i = cut[k]; i < cut[k + 1]; ++i) {
             const uint64_t j0 = job.square ? i + 1 : 0;
             uint64_t p = job.square ? dst_square_row_start(ncols, i) - dst_square_row_start(ncols, slab.rb)
@@ -555,14 +646,7 @@ void format_slab(const Job &job, Slab &slab)
             const std::string &row_id = job.rows->ids[i];
             const uint32_t *rc = job.row_counts ? job.row_counts + 4 * i : nullptr;
             for (uint64_t j = j0; j < ncols; ++j, ++p) {
-                double f = 0;
-                int64_t iv = 0;
-                const uint32_t *cc = job.col_counts ? job.col_counts + 4 * j : nullptr;
-                // record_1 = loaded / file-0 record, record_2 = the other (src/lib.rs:325, 432-434)
-                if (job.swap_ids)
-                    dst_finalize(job.measure, &slab.tallies[p * w], cc, rc, &f, &iv);
-                else
-                    dst_finalize(job.measure, &slab.tallies[p * w], rc, cc, &f, &iv);
+                const uint32_t *tl = &slab.tallies[p * w];
                 const std::string &id1 = job.swap_ids ? job.cols->ids[j] : row_id;
                 const std::string &id2 = job.swap_ids ? row_id : job.cols->ids[j];
                 out.ensure(id1.size() + id2.size() + 3 + cli::kFixed12Max);
@@ -573,7 +657,37 @@ void format_slab(const Job &job, Slab &slab)
                 std::memcpy(o, id2.data(), id2.size());
                 o += id2.size();
                 *o++ = '\t';
-                o += is_int ? cli::fmt_i64(iv, o) : cli::fmt_fixed12(f, o);
+                Memo *slot = nullptr;
+                uint64_t key_lo = 0;
+                uint32_t key_hi = 0;
+                if (memo_ok) {
+                    key_lo = (uint64_t)tl[0] | (uint64_t)tl[1] << 32;
+                    key_hi = w > 2 ? tl[2] : 0u;
+                    slot = &memo[(size_t)((key_lo * 0x9E3779B97F4A7C15ull ^ (uint64_t)key_hi * 0xC2B2AE3D27D4EB4Full) >> 50)];
+                    if (slot->len && slot->key_lo == key_lo && slot->key_hi == key_hi) {
+                        std::memcpy(o, slot->text, sizeof slot->text);  // fixed-size copy; only `len` bytes count
+                        o += slot->len;
+                        *o++ = '\n';
+                        out.len = (size_t)(o - out.p.get());
+                        continue;
+                    }
+                }
+                double f = 0;
+                int64_t iv = 0;
+                const uint32_t *cc = job.col_counts ? job.col_counts + 4 * j : nullptr;
+                // record_1 = loaded / file-0 record, record_2 = the other (src/lib.rs:325, 432-434)
+                if (job.swap_ids)
+                    dst_finalize(job.measure, tl, cc, rc, &f, &iv);
+                else
+                    dst_finalize(job.measure, tl, rc, cc, &f, &iv);
+                const int len = is_int ? cli::fmt_i64(iv, o) : cli::fmt_fixed12(f, o);
+                if (slot && (size_t)len <= sizeof slot->text) {
+                    slot->key_lo = key_lo;
+                    slot->key_hi = key_hi;
+                    slot->len = (uint8_t)len;
+                    std::memcpy(slot->text, o, (size_t)len);
+                }
+                o += len;
                 *o++ = '\n';
                 out.len = (size_t)(o - out.p.get());
             }
@@ -789,6 +903,42 @@ struct PhaseTimer {
     }
 };
 
+// num_cpus::get() (src/lib.rs:262): the CPUs this process may use — its affinity mask, capped by a cgroup CPU
+// quota when the container has one (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).
+static size_t available_cpus()
+{
+    size_t n = std::max<unsigned>(1, std::thread::hardware_concurrency());
+    auto quota = [](const char *path_quota, const char *path_period) -> double {
+        double q = -1, p = 100000;
+        if (FILE *fh = std::fopen(path_quota, "r")) {
+            char word[64] = {0};
+            if (path_period == nullptr) {  // "max 100000" or "1600000 100000"
+                double per = 0;
+                if (std::fscanf(fh, "%63s %lf", word, &per) == 2 && std::strcmp(word, "max") != 0) {
+                    q = std::atof(word);
+                    p = per;
+                }
+            } else if (std::fscanf(fh, "%lf", &q) != 1) {
+                q = -1;
+            }
+            std::fclose(fh);
+        }
+        if (path_period)
+            if (FILE *fh = std::fopen(path_period, "r")) {
+                if (std::fscanf(fh, "%lf", &p) != 1)
+                    p = 100000;
+                std::fclose(fh);
+            }
+        return (q > 0 && p > 0) ? q / p : -1.0;
+    };
+    double c = quota("/sys/fs/cgroup/cpu.max", nullptr);
+    if (c < 0)
+        c = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (c > 0)
+        n = std::min<size_t>(n, std::max<size_t>(1, (size_t)(c + 0.999)));
+    return n;
+}
+
 int main(int argc, char **argv)
 {
     PhaseTimer timer;
@@ -819,7 +969,7 @@ int main(int argc, char **argv)
     uint8_t table[256];
     encoding_array(table);
     const size_t threads = a.has_threads ? std::max<size_t>(a.threads, 1)  // src/lib.rs:253-263
-                                         : std::max<unsigned>(1, std::thread::hardware_concurrency());
+                                         : available_cpus();
     const size_t parse_threads = std::min<size_t>(threads, 16);
     std::vector<Alignment> loaded;
     for (size_t k = 0; k < files.size(); ++k) {  // load_fastas(): src/fastaio.rs:202-212

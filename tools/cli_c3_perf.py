@@ -21,7 +21,7 @@ with open(path, "wb") as fh:
         fh.write(synth.fasta_bytes(synth.SEED ^ 3, codes, first=r0))
 print(f"# wrote {path}: {os.path.getsize(path) / 1e9:.2f} GB in {time.time() - t0:.1f} s", flush=True)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "distance_amd", "cli", "distance")
-for args in (["-m", measure, path, "-o", "/dev/null"],):
+for args in (["-m", measure, path, "-o", "/dev/null"], ["-m", measure, path, "-o", "/dev/null", "-t", "16"], ["-m", measure, path, "-o", "/dev/null", "-t", "32"]):
     t0 = time.time()
     r = subprocess.run([cli] + args, env=dict(os.environ, DISTANCE_TIMING="1"), capture_output=True)
     dt = time.time() - t0
