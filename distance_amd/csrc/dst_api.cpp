@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -18,6 +19,8 @@ namespace dst {
 
 std::string g_create_err;
 std::mutex g_create_mu;
+
+int publish_prep(dst_ctx *ctx, hipStream_t stream);
 
 int fail(dst_ctx *ctx, int status, const std::string &msg)
 {
@@ -144,11 +147,10 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     if (s.have_counts)
         return DST_OK;
     HIP_TRY(ctx, launch_fill_counts(s, stream));
-    // complete before anyone is told the counts exist: later runs may be queued on OTHER streams
-    // (multi-GPU sub-slabs alternate between two) and would not be ordered after this kernel
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    // later runs may be queued on OTHER streams (multi-GPU sub-slabs alternate between two): they wait for this on
+    // the device (order_after_prep)
     s.have_counts = true;
-    return DST_OK;
+    return publish_prep(ctx, stream);
 }
 
 // Tile lists already on the device, keyed by the launch geometry (no host sync or H2D on a hit).
@@ -254,6 +256,53 @@ int ensure_lut(dst_ctx *ctx)
     return DST_OK;
 }
 
+// ---- ordering between streams without host synchronisation -----------------------------------------
+// Derived data (difference lists, per-record constants, hot columns, base counts) is built on the stream of the run
+// that first needs it.  A later run on ANOTHER stream waits for prep_event on the device; a rebuild first waits,
+// on the device, for the runs other streams still have in flight.  (r02 first used hipDeviceSynchronize /
+// hipStreamSynchronize here: six host round trips per step, 0.4 ms of a 0.9 ms step at 10,000 x 30,000.)
+int publish_prep(dst_ctx *ctx, hipStream_t stream)
+{
+    HIP_TRY(ctx, hipEventRecord(ctx->prep_event, stream));
+    ctx->prep_stream = stream;
+    ctx->prep_pending = true;
+    static const bool host_sync = std::getenv("DST_HOST_SYNC") != nullptr;  // measurement knob: the r02a behaviour
+    if (host_sync)
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return DST_OK;
+}
+
+int order_after_prep(dst_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->prep_pending && ctx->prep_stream != stream)
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->prep_event, 0));
+    return DST_OK;
+}
+
+int wait_for_other_runs(dst_ctx *ctx, hipStream_t stream)
+{
+    for (auto &r : ctx->recent)
+        if (r.used && r.stream != stream)
+            HIP_TRY(ctx, hipStreamWaitEvent(stream, r.event, 0));
+    return DST_OK;
+}
+
+int note_run(dst_ctx *ctx, hipStream_t stream)
+{
+    dst_ctx::Recent *slot = nullptr;
+    for (auto &r : ctx->recent)
+        if (r.used && r.stream == stream)
+            slot = &r;
+    if (!slot) {
+        slot = &ctx->recent[ctx->recent_next % 4];
+        ctx->recent_next += 1;
+    }
+    HIP_TRY(ctx, hipEventRecord(slot->event, stream));
+    slot->stream = stream;
+    slot->used = true;
+    return DST_OK;
+}
+
 // the reference sequence of `s` (plurality code per site over a sample of its records), its hot sites and the
 // statistics the path choice reads
 int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
@@ -289,7 +338,9 @@ int ensure_hot(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, hipStream_t stream
     const size_t n_hot = refset.ref.h_stats[4];
     if (s.hot && s.hot->loaded && s.hot_epoch == s.epoch && s.hot_ref_owner == &refset && s.hot_ref_epoch == refset.epoch)
         return DST_OK;
-    HIP_TRY(ctx, hipDeviceSynchronize());  // a run on another stream may still read the old columns
+    int rc0 = wait_for_other_runs(ctx, stream);  // a run on another stream may still read the old columns
+    if (rc0)
+        return rc0;
     if (!s.hot)
         s.hot = new (std::nothrow) DeviceSet;
     if (!s.hot)
@@ -298,7 +349,9 @@ int ensure_hot(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, hipStream_t stream
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_compact(s, refset.ref.hot_sites, (uint32_t)n_hot, *s.hot, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    rc = publish_prep(ctx, stream);
+    if (rc)
+        return rc;
     s.hot->loaded = true;
     s.hot_epoch = s.epoch;
     s.hot_ref_owner = &refset;
@@ -315,10 +368,12 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (lists_ok && (!want_sites || s.site.valid))
         return DST_OK;
     // other streams may still be reading the buffers about to be rebuilt
-    HIP_TRY(ctx, hipDeviceSynchronize());
+    int rc = wait_for_other_runs(ctx, stream);
+    if (rc)
+        return rc;
     const uint32_t n_panels = (uint32_t)((s.n + kPanelCols - 1) / kPanelCols);
     const size_t n_buckets = want_sites ? s.nchunks * kChunkSites * (size_t)n_panels : 0;
-    int rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
+    rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.cnt, &s.site.cnt_cap, (n_buckets + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
@@ -363,8 +418,10 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     }
     HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
                               ctx->site_cur, s.site.ent, n_panels, ctx->d_total, stream));
-    // complete before the lists are published: later runs may be queued on other streams
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    // runs queued on other streams wait for this on the device
+    rc = publish_prep(ctx, stream);
+    if (rc)
+        return rc;
     s.rec.valid = true;
     s.rec.ref_owner = &refset;
     s.rec.ref_epoch = refset.epoch;
@@ -383,12 +440,15 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
     if (s.aconst && s.aconst_family == family && s.aconst_wide == wide && s.aconst_epoch == s.epoch &&
         s.aconst_ref_owner == &refset && s.aconst_ref_epoch == refset.epoch)
         return DST_OK;
-    HIP_TRY(ctx, hipDeviceSynchronize());  // a run on another stream may still read the old words
-    int rc = ensure_bytes(ctx, (void **)&s.aconst, &s.aconst_cap, s.npad * kMaxWords * sizeof(uint32_t));
+    int rc = wait_for_other_runs(ctx, stream);  // a run on another stream may still read the old words
+    if (!rc)
+        rc = ensure_bytes(ctx, (void **)&s.aconst, &s.aconst_cap, s.npad * kMaxWords * sizeof(uint32_t));
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_aconst(s, family, wide, ctx->d_lut, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    rc = publish_prep(ctx, stream);
+    if (rc)
+        return rc;
     s.aconst_family = family;
     s.aconst_wide = wide;
     s.aconst_epoch = s.epoch;
@@ -470,6 +530,11 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         return fail(ctx, DST_ERR_ARG, "DST_OUT_TALLY16 needs alignments shorter than 65,536 sites");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    {   // data another run's stream derived (lists, constants, counts): wait for it on the device
+        const int rc_prep = order_after_prep(ctx, stream);
+        if (rc_prep)
+            return rc_prep;
+    }
     const uint64_t total_pairs = pairs_in_rows(square, cols.n, rb, re);
     const size_t need = dst_out_bytes(measure, out_kind, total_pairs);
     if (need > cap)
@@ -492,7 +557,9 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
     // hybrid of the two (hot columns dense, the rest by lists)
     int rc = DST_OK;
     int path = DST_PATH_DENSE;
-    if (ctx->path != DST_PATH_DENSE && consensus_shape_ok(rows, cols)) {
+    // a launch the dense kernels finish in less time than the lists take to set up goes dense unasked
+    const bool tiny = ctx->path == DST_PATH_AUTO && (double)total_pairs * (double)cols.len < 2.0e10 && !cols.ref.valid;
+    if (ctx->path != DST_PATH_DENSE && !tiny && consensus_shape_ok(rows, cols)) {
         rc = ensure_lut(ctx);
         if (!rc)
             rc = ensure_ref(ctx, cols, stream);
@@ -602,6 +669,9 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
                 HIP_TRY(ctx, hipEventRecord(ctx->hot_free, stream));
                 ctx->hot_used = true;
             }
+            rc = note_run(ctx, stream);  // a rebuild of the lists on another stream waits for this run
+            if (rc)
+                return rc;
         }
         if (!stream_v)
             HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -769,6 +839,11 @@ int dst_create(int device, dst_ctx **out)
         return bail(c, e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->hot_free, hipEventDisableTiming)) != hipSuccess)
         return bail(c, e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->prep_event, hipEventDisableTiming)) != hipSuccess)
+        return bail(c, e, "hipEventCreate");
+    for (auto &r : c->recent)
+        if ((e = hipEventCreateWithFlags(&r.event, hipEventDisableTiming)) != hipSuccess)
+            return bail(c, e, "hipEventCreate");
     *out = c;
     return DST_OK;
 }
@@ -795,6 +870,11 @@ int dst_destroy(dst_ctx *ctx)
         (void)hipEventDestroy(ctx->scratch_free);
     if (ctx->hot_free)
         (void)hipEventDestroy(ctx->hot_free);
+    if (ctx->prep_event)
+        (void)hipEventDestroy(ctx->prep_event);
+    for (auto &r : ctx->recent)
+        if (r.event)
+            (void)hipEventDestroy(r.event);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
     for (auto &ev : ctx->ev)

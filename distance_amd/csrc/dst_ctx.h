@@ -43,6 +43,16 @@ struct dst_ctx {
     size_t hot_tally_bytes = 0;
     hipEvent_t hot_free = nullptr;  // recorded after the last reader of `hot_tally`
     bool hot_used = false;
+    // cross-stream ordering of derived data (dst_api.cpp: publish_prep / order_after_prep / wait_for_other_runs)
+    hipEvent_t prep_event = nullptr;
+    hipStream_t prep_stream = nullptr;
+    bool prep_pending = false;
+    struct Recent {
+        hipStream_t stream = nullptr;
+        hipEvent_t event = nullptr;
+        bool used = false;
+    } recent[4];
+    unsigned recent_next = 0;
     void *host_out = nullptr;  // device staging of the *_host run forms (grow-only)
     size_t host_out_bytes = 0;
     int ksplit = 0;  // 0 = automatic split-L factor, >= 1 forced
