@@ -477,6 +477,12 @@ struct FWords {
     uint32_t w[kMaxWords];
 };
 
+constexpr int kEventWaves = 4;                     // event waves per workgroup (beside the 4 output waves)
+constexpr uint32_t kEventLanes = 64 * kEventWaves;  // entries of a batch the register pipeline carries
+
+// the value must be in its register HERE (an empty asm the compiler cannot move a definition across)
+__device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
+
 struct __attribute__((packed, aligned(8))) F64x2 {  // two adjacent results, 8-byte aligned: one 16-byte store
     double a, b;
 };
@@ -500,7 +506,7 @@ struct __attribute__((packed, aligned(8))) I64x2 {
 // wave that has just issued its result stores cannot consume a younger load before those stores have
 // landed in HBM; the event waves' chains of dependent random loads never queue behind a store this way.
 template <int FAM, bool WIDE, int OUT>
-__global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
+__global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
     const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint2 *__restrict__ site_tab,
     const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
@@ -527,9 +533,9 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
     const uint32_t tid = threadIdx.x & 255u, lane = tid & 63u;
     const uint32_t trows = tile.i1 - tile.i0;              // <= kTileRowsMax
     const uint32_t nbatch = (trows + RB - 1) / RB;
-    for (uint32_t k = threadIdx.x; k < 2 * ACC; k += 512)
+    for (uint32_t k = threadIdx.x; k < 2 * ACC; k += blockDim.x)
         acc[k] = 0;
-    for (uint32_t k = threadIdx.x; k < kRefClasses * 256 * W; k += 512)
+    for (uint32_t k = threadIdx.x; k < kRefClasses * 256 * W; k += blockDim.x)
         hlut[k] = (&lut->h[FAM][WIDE ? 1 : 0][0][0][0][0])[(k / W) * kMaxWords + k % W];
     if (threadIdx.x <= trows)
         rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
@@ -545,8 +551,12 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
             for (int h = 0; h < 2; ++h) {
                 const uint32_t k = 2 * tid + 512 * j + h;
 #pragma unroll
-                for (int w = 0; w < W; ++w)
+                for (int w = 0; w < W; ++w) {
                     ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+                    // keep the VALUE in a register: left to itself hipcc re-loads it inside the output loop, and on
+                    // gfx950 waiting for that load (vmcnt) also waits for every result store issued before it
+                    asm volatile("" : "+v"(ca[j][h][w]));
+                }
             }
     }
     __syncthreads();
@@ -594,18 +604,20 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
     auto apply_bucket = [&](const Bucket &bk, const uint4 *ce, uint32_t b) {
         const uint32_t q0 = tile.i0 + b * RB;
         uint32_t *bacc = acc + (b & 1u) * ACC;
-        // one candidate event: column record + nibble from the bucket, h_k from the table, into the accumulators
+        // one candidate event: column record + nibble from the bucket, h_k from the table, into the accumulators.
+        // meta = row of the batch << 8 | (reference class << 4 | row nibble): the table row and the accumulator
+        // row are per-entry values; per event there is the column's nibble and its place in the panel (the low 11
+        // bits of the record: panels are 2,048-aligned).  Only tiles on the diagonal have to test t > q.
+        const bool diag = square && panel0 <= tile.i1;
         auto apply = [&](uint32_t c, uint32_t meta) {
-            const uint32_t t = c & kEntryMask, rb = meta >> 8;
-            if (!square || t > q0 + rb) {
-                const uint32_t *h = hlut + (((meta & 255u) << 4) | (c >> kEntryShift)) * W;
+            const uint32_t rb = meta >> 8;
+            if (diag && (c & kEntryMask) <= q0 + rb)
+                return;
+            const uint32_t *h = hlut + (((meta & 255u) << 4) | (c >> kEntryShift)) * W;
+            uint32_t *a = bacc + rb * W * kPanelCols + (c & (kPanelCols - 1));
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const uint32_t v = h[w];
-                    if (v)
-                        atomicAdd(&bacc[(rb * W + w) * kPanelCols + (t - panel0)], v);
-                }
-            }
+            for (int w = 0; w < W; ++w)
+                atomicAdd(&a[w * kPanelCols], h[w]);   // adding 0 is cheaper than testing for it
         };
 #pragma unroll
         for (int j = 0; j < INL / 4; ++j) {
@@ -659,20 +671,31 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
                 apply_bucket(bk_cur, ce_cur, step);
                 // entries beyond the 256 the pipeline carries (long lists): plain slices
                 const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
-                for (uint32_t first = 256; first < run; first += 256) {
+                for (uint32_t first = kEventLanes; first < run; first += kEventLanes) {
                     const Bucket bk = load_bucket(load_entry(step, first));
                     uint4 ce[INL / 4];
                     load_events(bk, ce);
                     apply_bucket(bk, ce, step);
                 }
-                // rotate the pipeline and issue the next loads (consumed one step later each)
+                // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
+                // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
+                // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
+                // loads it has just issued: no overlap at all.  pin() fixes the copies in place, the scheduling
+                // barrier keeps the loads below them.
                 bk_cur = bk_nx;
 #pragma unroll
                 for (int j = 0; j < INL / 4; ++j)
                     ce_cur[j] = ce_nx[j];
                 bk_nx = bk_n2;
+                Entry en_use = en_n3;
+                pin(bk_cur.o0), pin(bk_cur.cnt), pin(bk_cur.meta), pin(bk_nx.o0), pin(bk_nx.cnt), pin(bk_nx.meta);
+                pin(en_use.e), pin(en_use.rb);
+#pragma unroll
+                for (int j = 0; j < INL / 4; ++j)
+                    pin(ce_cur[j].x), pin(ce_cur[j].y), pin(ce_cur[j].z), pin(ce_cur[j].w);
+                __builtin_amdgcn_sched_barrier(0);
                 load_events(bk_nx, ce_nx);
-                bk_n2 = load_bucket(en_n3);
+                bk_n2 = load_bucket(en_use);
                 en_n3 = load_entry(step + 4, 0);
             }
         } else if (step >= 1) {
@@ -791,7 +814,12 @@ __global__ __launch_bounds__(512, OUT == DST_TN93 ? 4 : 2) void consensus_pair_k
                 }
             }
         }
-        __syncthreads();
+        // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory:
+        // hipcc puts s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all
+        // their result stores have landed in HBM and the event waves wait for the loads they have just issued for
+        // the coming batches.  Nothing in global memory is handed between the waves of this kernel, so only the
+        // LDS traffic (lgkmcnt) has to be complete.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -936,7 +964,7 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(512), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
+    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(256 + 64 * kEventWaves), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
                        cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.tab, cl.cols->site.ent,
                        cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
