@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdistance_hip.so")
+LIB_PATH = os.environ.get("DST_LIB_PATH") or os.path.join(_HERE, "libdistance_hip.so")   # DST_LIB_PATH: measurement builds (tools/variants.sh)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "distance_hip.h")
 
 _u8p = C.POINTER(C.c_uint8)

@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 void free_set(DeviceSet &s)
 {
     void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent,
-                    s.site.cnt, s.site.off, s.site.tab, s.site.ent, s.aconst};
+                    s.site.cnt, s.site.off, s.site.tab, s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -381,6 +381,8 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.tab, &s.site.tab_cap, std::max<size_t>(n_buckets, 1) * sizeof(uint2));
     if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.inl, &s.site.inl_cap, std::max<size_t>(n_buckets, 1) * 2 * sizeof(uint4));
+    if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&ctx->site_cur, &ctx->site_cur_bytes, (n_buckets + 1) * sizeof(uint32_t));
     if (!rc)
         rc = ensure_bytes(ctx, (void **)&ctx->scan_tmp, &ctx->scan_tmp_bytes,
@@ -395,7 +397,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
     HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, want_sites, false, s.rec.off, nullptr, s.site.cnt, nullptr,
-                              nullptr, n_panels, ctx->d_total, stream));
+                              nullptr, nullptr, n_panels, ctx->d_total, stream));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -413,11 +415,11 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (want_sites) {
         HIP_TRY(ctx, launch_pad_counts(s.site.cnt, s.site.off, n_buckets, stream));
         HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
-        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
+        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, s.site.inl, n_buckets, stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->site_cur, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
     }
     HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
-                              ctx->site_cur, s.site.ent, n_panels, ctx->d_total, stream));
+                              ctx->site_cur, s.site.ent, want_sites ? s.site.inl : nullptr, n_panels, ctx->d_total, stream));
     // runs queued on other streams wait for this on the device
     rc = publish_prep(ctx, stream);
     if (rc)
@@ -1094,7 +1096,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e == hipSuccess)
         e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
@@ -1122,7 +1124,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
         return done(DST_OK);
     e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                                     int skip_nclass, uint32_t *__restrict__ rec,
                                                     uint32_t *__restrict__ rec_ent, uint32_t *__restrict__ site,
                                                     uint32_t *__restrict__ site_cur,
-                                                    uint32_t *__restrict__ site_ent, uint32_t n_panels,
-                                                    unsigned long long *__restrict__ total)
+                                                    uint32_t *__restrict__ site_ent, uint16_t *__restrict__ site_inl,
+                                                    uint32_t n_panels, unsigned long long *__restrict__ total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t rl = lane & 7u, cl = lane >> 3;
@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                             const size_t bk = (size_t)panel * ((size_t)nchunks * kChunkSites) + s;
                             const uint32_t pos = atomicAdd(&site_cur[bk], 1u);
                             site_ent[site[bk] + pos] = r | nib << kEntryShift;
+                            if (pos < kInlineEvents)   // the lookup-table entry itself holds the first entries
+                                site_inl[bk * 16 + 1 + pos] = (uint16_t)((r & (kPanelCols - 1u)) | nib << 11);
                         }
                     } else if (want_sites) {
                         atomicAdd(&site[(size_t)panel * ((size_t)nchunks * kChunkSites) + s], 1u);
@@ -388,11 +390,13 @@ __global__ __launch_bounds__(256) void pad_counts_kernel(const uint32_t *__restr
 }
 
 __global__ __launch_bounds__(256) void site_table_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt,
-                                                          uint2 *__restrict__ tab, size_t n)
+                                                          uint2 *__restrict__ tab, uint16_t *__restrict__ inl, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
+    if (i < n) {
         tab[i] = make_uint2(off[i], cnt[i]);
+        inl[i * 16] = (uint16_t)min(cnt[i], 0xFFFFu);   // halfword 0 of the 32-byte entry; the fill pass writes 1..15
+    }
 }
 
 // =============================================================================================
@@ -477,18 +481,56 @@ struct FWords {
     uint32_t w[kMaxWords];
 };
 
+// which instantiations write their results in address-aligned quarters (see ALIGNED in the kernel): the single-word
+// families whose time is the result stream itself; jc69's output phase is bound by its f64 logarithm instead
+template <int FAM, bool WIDE, int OUT>
+constexpr bool aligned_output()
+{
+#ifdef DST_DBG_OLDMAP
+    return false;
+#else
+    return Pack<FAM, WIDE>::W == 1 && OUT != DST_JC69;
+#endif
+}
+
 constexpr int kEventWaves = 4;                     // event waves per workgroup (beside the 4 output waves)
 constexpr uint32_t kEventLanes = 64 * kEventWaves;  // entries of a batch the register pipeline carries
 
 // the value must be in its register HERE (an empty asm the compiler cannot move a definition across)
 __device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
 
-struct __attribute__((packed, aligned(8))) F64x2 {  // two adjacent results, 8-byte aligned: one 16-byte store
-    double a, b;
-};
-struct __attribute__((packed, aligned(8))) I64x2 {
-    int64_t a, b;
-};
+// Two adjacent results, 8-byte aligned: one 16-byte store — NONTEMPORAL: the results are written once and never read
+// by this kernel; left to the default policy the 10 GB result stream of a 50,000-record run evicts the lookup tables
+// the event waves gather from out of the L2 (raw, 50,000 x 30,000: 3.2 ms with plain stores, 2.5 ms with these).
+typedef double F64x2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef long long I64x2 __attribute__((ext_vector_type(2), aligned(8)));
+template <typename T>
+__device__ __forceinline__ void store_result(T *p, T v)
+{
+#ifdef DST_DBG_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+__device__ __forceinline__ void store_result2(double *p, double a, double b)
+{
+    F64x2 v = {a, b};
+#ifdef DST_DBG_PLAIN_STORES
+    *reinterpret_cast<F64x2 *>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<F64x2 *>(p));
+#endif
+}
+__device__ __forceinline__ void store_result2(int64_t *p, int64_t a, int64_t b)
+{
+    I64x2 v = {(long long)a, (long long)b};
+#ifdef DST_DBG_PLAIN_STORES
+    *reinterpret_cast<I64x2 *>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<I64x2 *>(p));
+#endif
+}
 
 // One block = rows [i0, i1) x one panel of up to kPanelCols column records; the rows go through kAccRows at a
 // time (a "batch"; their lists are adjacent in the CSR, so a batch is one run of entries).  512 threads in two
@@ -508,8 +550,8 @@ struct __attribute__((packed, aligned(8))) I64x2 {
 template <int FAM, bool WIDE, int OUT>
 __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
-    const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint2 *__restrict__ site_tab,
-    const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
+    const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint4 *__restrict__ site_inl,
+    const uint2 *__restrict__ site_tab, const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
     uint32_t n_sites, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
     const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square,
@@ -517,14 +559,25 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
 {
     using P = Pack<FAM, WIDE>;
     constexpr int W = P::W, NT = P::NT;
+#ifdef DST_DBG_RB
+    constexpr int RB = DST_DBG_RB;
+#else
     constexpr int RB = kAccRows;
+#endif
     constexpr int PAIRS = kPanelCols / 512;      // column pairs per output thread
-    constexpr int INL = 8;                        // events a lane applies for its own entry before the wave shares the rest
     constexpr uint32_t ACC = RB * W * kPanelCols;  // words of one accumulator buffer
     extern __shared__ uint32_t smem[];
     uint32_t *acc = smem;                                  // [2][RB][W][kPanelCols]
     uint32_t *hlut = smem + 2 * ACC;                       // [kRefClasses][16][16][W]: h_k of this family
     uint32_t *rofs = hlut + kRefClasses * 256 * W;         // [kTileRowsMax + 1] list offsets of the tile's rows
+    // Single-word families (n, n_high, raw, jc69 below 65,536 sites) are bound by WRITING the results, and the
+    // write rate depends on the store pattern (tools/ubench/store_rate.hip on MI355X, 10 GB triangle: every output
+    // wave storing 1 KB pieces 4 KB apart from an 8-byte-aligned row start 3.5-3.9 TB/s; each wave one contiguous
+    // quarter of the row cut at 128-byte lines of the absolute address 4.7-5.1 TB/s = the rate of a plain aligned
+    // fill).  So for them (ALIGNED) a thread's columns follow the ADDRESS of the row, not the panel, and A(column)
+    // comes from an LDS copy of the panel's constants instead of registers.
+    constexpr bool ALIGNED = aligned_output<FAM, WIDE, OUT>();
+    uint32_t *cola = rofs + kTileRowsMax + 1;              // ALIGNED: [kPanelCols] A(column) of this panel
 
     const ConsensusTile tile = tiles[blockIdx.x];
     const uint32_t panel0 = tile.panel * kPanelCols;
@@ -539,10 +592,13 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         hlut[k] = (&lut->h[FAM][WIDE ? 1 : 0][0][0][0][0])[(k / W) * kMaxWords + k % W];
     if (threadIdx.x <= trows)
         rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
+    if constexpr (ALIGNED)
+        for (uint32_t k = threadIdx.x; k < kPanelCols; k += blockDim.x)
+            cola[k] = k < pcols ? col_a[panel0 + k] : 0u;
     // A(column) of an output thread's column pairs: constant over the rows of the tile, kept in registers —
     // except for tn93, whose finalisation needs the registers more (there the 4 bytes are re-read per pair
     // and the pair loop stays rolled: one copy of the formula in the code)
-    constexpr bool HOIST = OUT != DST_TN93;
+    constexpr bool HOIST = OUT != DST_TN93 && !ALIGNED;
     uint32_t ca[HOIST ? PAIRS : 1][2][W];
     if constexpr (HOIST) {
 #pragma unroll
@@ -567,8 +623,9 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         uint32_t e, rb;
         bool valid;
     };
-    struct Bucket {  // stage 2: its bucket in this panel
-        uint32_t o0, cnt, meta;
+    struct Inl {     // stage 2: the 32-byte lookup-table entry of its site in this panel = the bucket itself
+        uint4 lo, hi;        // halfword 0: entries in the bucket (saturating); halfwords 1..15: record-in-panel | nibble << 11
+        uint32_t meta, site;
     };
     auto load_entry = [&](uint32_t b, uint32_t first) {   // entry `first + tid` of batch b's run
         Entry en{0u, 0u, false};
@@ -585,49 +642,56 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         }
         return en;
     };
-    auto load_bucket = [&](const Entry &en) {
-        Bucket bk{0u, 0u, 0u};
+    auto load_inl = [&](const Entry &en) {
+        Inl t{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u, 0u};
         if (en.valid) {
-            const uint2 tab = site_tab[(size_t)tile.panel * n_sites + (en.e & kSiteMask)];
-            bk.o0 = tab.x;
-            bk.cnt = tab.y;
-            bk.meta = en.rb << 8 | ((en.e >> kSiteBits) & 7u) << 4 | (en.e >> kEntryShift);
+            t.site = en.e & kSiteMask;
+            const uint4 *p = site_inl + 2 * ((size_t)tile.panel * n_sites + t.site);
+            t.lo = p[0];
+            t.hi = p[1];
+            t.meta = en.rb << 8 | ((en.e >> kSiteBits) & 7u) << 4 | (en.e >> kEntryShift);
         }
-        return bk;
+        return t;
     };
-    auto load_events = [&](const Bucket &bk, uint4 *ce) {
-#pragma unroll
-        for (int j = 0; j < INL / 4; ++j)
-            ce[j] = (uint32_t)(4 * j) < bk.cnt ? reinterpret_cast<const uint4 *>(site_ent + bk.o0)[j] : make_uint4(0, 0, 0, 0);
-    };
-    // B for one lane's bucket of batch b: the first INL events from registers, the rest shared out over the wave
-    auto apply_bucket = [&](const Bucket &bk, const uint4 *ce, uint32_t b) {
+    // B for one lane's bucket of batch b: up to kInlineEvents events straight from the table entry; what a larger
+    // bucket holds beyond them comes from the bucket array, shared out over the wave
+    auto apply_bucket = [&](const Inl &t, uint32_t b) {
         const uint32_t q0 = tile.i0 + b * RB;
         uint32_t *bacc = acc + (b & 1u) * ACC;
         // one candidate event: column record + nibble from the bucket, h_k from the table, into the accumulators.
         // meta = row of the batch << 8 | (reference class << 4 | row nibble): the table row and the accumulator
-        // row are per-entry values; per event there is the column's nibble and its place in the panel (the low 11
-        // bits of the record: panels are 2,048-aligned).  Only tiles on the diagonal have to test t > q.
+        // row are per-entry values; per event there is the column's nibble and its place in the panel.
+        // Only tiles on the diagonal have to test t > q.
         const bool diag = square && panel0 <= tile.i1;
-        auto apply = [&](uint32_t c, uint32_t meta) {
-            const uint32_t rb = meta >> 8;
-            if (diag && (c & kEntryMask) <= q0 + rb)
+        auto apply = [&](uint32_t col, uint32_t nib, uint32_t meta) {
+#ifdef DST_DBG_NO_APPLY
+            if (col != 0xFFFFFFFFu)
                 return;
-            const uint32_t *h = hlut + (((meta & 255u) << 4) | (c >> kEntryShift)) * W;
-            uint32_t *a = bacc + rb * W * kPanelCols + (c & (kPanelCols - 1));
+#endif
+            const uint32_t rb = meta >> 8;
+            if (diag && panel0 + col <= q0 + rb)
+                return;
+            const uint32_t *h = hlut + (((meta & 255u) << 4) | nib) * W;
+            uint32_t *a = bacc + rb * W * kPanelCols + col;
 #pragma unroll
             for (int w = 0; w < W; ++w)
                 atomicAdd(&a[w * kPanelCols], h[w]);   // adding 0 is cheaper than testing for it
         };
+        const uint32_t cnt = t.lo.x & 0xFFFFu;
+        const uint32_t w8[8] = {t.lo.x, t.lo.y, t.lo.z, t.lo.w, t.hi.x, t.hi.y, t.hi.z, t.hi.w};
 #pragma unroll
-        for (int j = 0; j < INL / 4; ++j) {
-            if ((uint32_t)(4 * j + 0) < bk.cnt) apply(ce[j].x, bk.meta);
-            if ((uint32_t)(4 * j + 1) < bk.cnt) apply(ce[j].y, bk.meta);
-            if ((uint32_t)(4 * j + 2) < bk.cnt) apply(ce[j].z, bk.meta);
-            if ((uint32_t)(4 * j + 3) < bk.cnt) apply(ce[j].w, bk.meta);
-        }
-        const uint32_t ex = bk.cnt > INL ? bk.cnt - INL : 0u;
-        if (__ballot(ex != 0)) {
+        for (uint32_t k = 1; k <= kInlineEvents; ++k)
+            if (k <= cnt) {
+                const uint32_t e16 = (k & 1u) ? w8[k >> 1] >> 16 : w8[k >> 1] & 0xFFFFu;
+                apply(e16 & (kPanelCols - 1u), e16 >> 11, t.meta);
+            }
+        if (__ballot(cnt > kInlineEvents)) {
+            uint32_t o0 = 0, ex = 0;
+            if (cnt > kInlineEvents) {
+                const uint2 tab = site_tab[(size_t)tile.panel * n_sites + t.site];
+                o0 = tab.x + kInlineEvents;
+                ex = tab.y - kInlineEvents;
+            }
             uint32_t incl = ex, up;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -643,62 +707,63 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                     const uint32_t v = __shfl(start, (int)(lo + st));
                     if (v <= i) lo += st;   // the last lane whose range starts at or before i (sizes may be 0)
                 }
-                const uint32_t s_o0 = __shfl(bk.o0, (int)lo), s_meta = __shfl(bk.meta, (int)lo), s_start = __shfl(start, (int)lo);
-                if (i < total)
-                    apply(site_ent[s_o0 + INL + (i - s_start)], s_meta);
+                const uint32_t s_o0 = __shfl(o0, (int)lo), s_meta = __shfl(t.meta, (int)lo), s_start = __shfl(start, (int)lo);
+                if (i < total) {
+                    const uint32_t c = site_ent[s_o0 + (i - s_start)];
+                    apply(c & (kPanelCols - 1u), c >> kEntryShift, s_meta);
+                }
             }
         }
     };
-    Entry en_n3{0u, 0u, false};
-    Bucket bk_cur{0u, 0u, 0u}, bk_nx{0u, 0u, 0u}, bk_n2{0u, 0u, 0u};
-    uint4 ce_cur[INL / 4], ce_nx[INL / 4];
-#pragma unroll
-    for (int j = 0; j < INL / 4; ++j)
-        ce_cur[j] = ce_nx[j] = make_uint4(0, 0, 0, 0);
-    if (event_role) {  // prologue: batch 0 fully staged, batch 1's bucket entries, batch 2's bucket, batch 3's entry
-        bk_cur = load_bucket(load_entry(0, 0));
-        load_events(bk_cur, ce_cur);
-        bk_nx = load_bucket(load_entry(1, 0));
-        load_events(bk_nx, ce_nx);
-        bk_n2 = load_bucket(load_entry(2, 0));
-        en_n3 = load_entry(3, 0);
-    }
-
-    for (uint32_t step = 0; step <= nbatch; ++step) {
-        if (event_role) {
-            if (step < nbatch) {
+    // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory: hipcc puts
+    // s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all their result
+    // stores have landed in HBM and the event waves wait for the loads they have just issued for the coming batches.
+    // Nothing in global memory is handed between the waves of this kernel, so only the LDS traffic (lgkmcnt) has to be
+    // complete.  The two roles run SEPARATE loops with the same number of barriers (s_barrier counts arrivals, it
+    // does not care where a wave stands): the event pipeline's registers are then not live in the output code and
+    // the other way round — the kernel needs the larger of the two register sets, not their sum.
+#define DST_BATCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (event_role) {
+        const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u, 0u};
+        Entry en_n2{0u, 0u, false};
+        Inl in_cur = inl_none, in_nx = inl_none;
+#ifdef DST_DBG_NO_EVENTS
+        const bool do_events = false;
+#else
+        const bool do_events = true;
+#endif
+        if (do_events) {  // prologue: batch 0's and batch 1's table entries, batch 2's list entry
+            in_cur = load_inl(load_entry(0, 0));
+            in_nx = load_inl(load_entry(1, 0));
+            en_n2 = load_entry(2, 0);
+        }
+        for (uint32_t step = 0; step <= nbatch; ++step) {
+            if (step < nbatch && do_events) {
                 // ---- B of batch `step` into buffer step & 1
-                apply_bucket(bk_cur, ce_cur, step);
+                apply_bucket(in_cur, step);
                 // entries beyond the 256 the pipeline carries (long lists): plain slices
                 const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
-                for (uint32_t first = kEventLanes; first < run; first += kEventLanes) {
-                    const Bucket bk = load_bucket(load_entry(step, first));
-                    uint4 ce[INL / 4];
-                    load_events(bk, ce);
-                    apply_bucket(bk, ce, step);
-                }
+                for (uint32_t first = kEventLanes; first < run; first += kEventLanes)
+                    apply_bucket(load_inl(load_entry(step, first)), step);
                 // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
                 // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
                 // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
                 // loads it has just issued: no overlap at all.  pin() fixes the copies in place, the scheduling
                 // barrier keeps the loads below them.
-                bk_cur = bk_nx;
-#pragma unroll
-                for (int j = 0; j < INL / 4; ++j)
-                    ce_cur[j] = ce_nx[j];
-                bk_nx = bk_n2;
-                Entry en_use = en_n3;
-                pin(bk_cur.o0), pin(bk_cur.cnt), pin(bk_cur.meta), pin(bk_nx.o0), pin(bk_nx.cnt), pin(bk_nx.meta);
-                pin(en_use.e), pin(en_use.rb);
-#pragma unroll
-                for (int j = 0; j < INL / 4; ++j)
-                    pin(ce_cur[j].x), pin(ce_cur[j].y), pin(ce_cur[j].z), pin(ce_cur[j].w);
+                in_cur = in_nx;
+                Entry en_use = en_n2;
+                pin(in_cur.lo.x), pin(in_cur.lo.y), pin(in_cur.lo.z), pin(in_cur.lo.w);
+                pin(in_cur.hi.x), pin(in_cur.hi.y), pin(in_cur.hi.z), pin(in_cur.hi.w);
+                pin(in_cur.meta), pin(in_cur.site), pin(en_use.e), pin(en_use.rb);
                 __builtin_amdgcn_sched_barrier(0);
-                load_events(bk_nx, ce_nx);
-                bk_n2 = load_bucket(en_use);
-                en_n3 = load_entry(step + 4, 0);
+                in_nx = load_inl(en_use);
+                en_n2 = load_entry(step + 3, 0);
             }
-        } else if (step >= 1) {
+            DST_BATCH_BARRIER();
+        }
+    } else {
+        for (uint32_t step = 0; step <= nbatch; ++step) {
+            if (step >= 1) {
             // ---- C of batch step - 1 from buffer (step - 1) & 1: constants, finalisation, canonical-order store
             const uint32_t b = step - 1, q0 = tile.i0 + b * RB;
             const uint32_t nrows = min((uint32_t)RB, tile.i1 - q0);
@@ -714,46 +779,53 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                 const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
                                                : (uint64_t)(q - row_begin) * n_cols;
                 uint32_t *racc = acc + (b & 1u) * ACC + rb * W * kPanelCols;
-                auto do_pair = [&](int j) {
-                    const uint32_t k = 2 * tid + 512 * j;
-                    if (k >= pcols)
-                        return;
-                    const uint32_t t = panel0 + k;
-                    const bool live[2] = {!square || t > q, k + 1 < pcols && (!square || t + 1 > q)};
+                // two adjacent results of row q: columns panel0 + ks and panel0 + ks + 1 (ks may be -1 .. pcols - 1:
+                // ALIGNED pairs straddle the panel's edges); j: the thread's register copy of A(column) (HOIST)
+                auto do_pair = [&](int32_t ks, int j) {
+                    bool in[2], live[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        in[h] = (uint32_t)(ks + h) < pcols;
+                        live[h] = in[h] && (!square || panel0 + (uint32_t)(ks + h) > q);
+                    }
                     if (!live[1] && !live[0])
-                        return;  // square: the whole pair lies at or below the diagonal (accumulators stay 0 there)
+                        return;  // outside the panel, or square: at or below the diagonal (accumulators stay 0 there)
+                    const uint64_t at = row_at + panel0 + (uint64_t)(int64_t)ks;   // modulo 2^64: right wherever live
                     uint32_t o[2][NT];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
+                        const uint32_t k = in[h] ? (uint32_t)(ks + h) : 0u;
                         uint32_t tot[W];
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
-                            const uint32_t a = racc[w * kPanelCols + k + h];
-                            if (a)
-                                racc[w * kPanelCols + k + h] = 0;
+                            const uint32_t a = racc[w * kPanelCols + k];
+                            if (a && in[h])
+                                racc[w * kPanelCols + k] = 0;
                             uint32_t cav;
-                            if constexpr (HOIST)
+                            if constexpr (ALIGNED)
+                                cav = cola[k];
+                            else if constexpr (HOIST)
                                 cav = ca[j][h][w];
                             else
-                                cav = k + h < pcols ? col_a[(size_t)w * col_npad + t + h] : 0u;
+                                cav = in[h] ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
                             tot[w] = a + cav + aq[w];
                         }
                         if (hot && live[h])
-                            P::add_hot(tot, hot, row_at + t + h);   // hybrid path: the dense kernels' tallies of the hot columns
+                            P::add_hot(tot, hot, at + h);   // hybrid path: the dense kernels' tallies of the hot columns
                         P::unpack(tot, o[h]);
                     }
-                    const uint64_t at = row_at + t;
                     if constexpr (OUT == OUT_INT) {
                         int64_t *out = static_cast<int64_t *>(out_v);
+#ifdef DST_DBG_NO_STORE
+                        if (o[0][0] != 0xFFFFFFF0u)
+                            return;
+#endif
                         if (live[0] && live[1]) {
-                            I64x2 v;
-                            v.a = (int64_t)o[0][0];
-                            v.b = (int64_t)o[1][0];
-                            *reinterpret_cast<I64x2 *>(out + at) = v;
+                            store_result2(out + at, (int64_t)o[0][0], (int64_t)o[1][0]);
                         } else if (live[0]) {
-                            out[at] = (int64_t)o[0][0];
+                            store_result(out + at, (int64_t)o[0][0]);
                         } else {
-                            out[at + 1] = (int64_t)o[1][0];
+                            store_result(out + at + 1, (int64_t)o[1][0]);
                         }
                     } else if constexpr (OUT == OUT_TALLY) {
                         uint32_t *out = static_cast<uint32_t *>(out_v);
@@ -762,7 +834,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                             if (live[h])
 #pragma unroll
                                 for (int x = 0; x < NT; ++x)
-                                    out[(at + h) * NT + x] = o[h][x];
+                                    store_result(out + (at + h) * NT + x, o[h][x]);
                     } else if constexpr (OUT == OUT_TALLY16) {
                         uint16_t *out = static_cast<uint16_t *>(out_v);
 #pragma unroll
@@ -770,16 +842,25 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                             if (live[h])
 #pragma unroll
                                 for (int x = 0; x < NT; ++x)
-                                    out[(at + h) * NT + x] = (uint16_t)o[h][x];
+                                    store_result(out + (at + h) * NT + x, (uint16_t)o[h][x]);
                     } else {
                         double *out = static_cast<double *>(out_v);
                         double d[2] = {0.0, 0.0};
                         auto fin = [&](int h) {
-                            if (live[h]) {
+                            // h may be a run-time value (tn93's rolled loop): selects, not indexed private arrays
+                            uint32_t oh[NT];
+#pragma unroll
+                            for (int x = 0; x < NT; ++x)
+                                oh[x] = h == 0 ? o[0][x] : o[1][x];
+                            if (h == 0 ? live[0] : live[1]) {
                                 uint4 tc = make_uint4(0, 0, 0, 0);
                                 if constexpr (OUT == DST_TN93)
-                                    tc = reinterpret_cast<const uint4 *>(t_counts)[t + h];
-                                d[h] = finalize_pair<OUT>(o[h], qc, tc);
+                                    tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
+                                const double r = finalize_pair<OUT>(oh, qc, tc);
+                                if (h == 0)
+                                    d[0] = r;
+                                else
+                                    d[1] = r;
                             }
                         };
                         if constexpr (OUT == DST_TN93) {
@@ -791,36 +872,48 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                             fin(0);
                             fin(1);
                         }
+#ifdef DST_DBG_NO_STORE
+                        if (d[0] != -12345.5)
+                            return;
+#endif
                         if (live[0] && live[1]) {
-                            F64x2 v;
-                            v.a = d[0];
-                            v.b = d[1];
-                            *reinterpret_cast<F64x2 *>(out + at) = v;
+                            store_result2(out + at, d[0], d[1]);
                         } else if (live[0]) {
-                            out[at] = d[0];
+                            store_result(out + at, d[0]);
                         } else {
-                            out[at + 1] = d[1];
+                            store_result(out + at + 1, d[1]);
                         }
                     }
                 };
-                if constexpr (HOIST) {
+                if constexpr (ALIGNED) {
+                    // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
+                    // or 17 lines-of-1-KB groups from that line's start go to the four output waves as contiguous
+                    // runs of 4 (one wave, rotating with the row, takes 5): a wave's stores are whole, consecutive
+                    // lines; only the panel's two edge lines are shared with the neighbouring tiles.
+                    constexpr uint32_t ELEM = OUT == OUT_TALLY ? 4u * NT : OUT == OUT_TALLY16 ? 2u * NT : 8u;
+                    const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(out_v) / ELEM + row_at + panel0) & 15u);
+                    const uint32_t wv = tid >> 6, extra = q & 3u;
+                    const uint32_t g0 = 4u * wv + (wv > extra ? 1u : 0u);
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g)
+                        do_pair((int32_t)(128u * (g0 + g) + 2u * lane) - (int32_t)sh, 0);
+                    if (wv == extra)
+                        do_pair((int32_t)(128u * (g0 + 4u) + 2u * lane) - (int32_t)sh, 0);
+                } else if constexpr (HOIST) {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair(j);
+                        do_pair((int32_t)(2 * tid + 512 * j), j);
                 } else {
 #pragma unroll 1
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair(j);
+                        do_pair((int32_t)(2 * tid + 512 * j), j);
                 }
             }
         }
-        // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory:
-        // hipcc puts s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all
-        // their result stores have landed in HBM and the event waves wait for the loads they have just issued for
-        // the coming batches.  Nothing in global memory is handed between the waves of this kernel, so only the
-        // LDS traffic (lgkmcnt) has to be complete.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DST_BATCH_BARRIER();
+        }
     }
+#undef DST_BATCH_BARRIER
 }
 
 // =============================================================================================
@@ -888,17 +981,17 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
                         bool skip_nclass,
                         uint32_t *rec, uint32_t *rec_ent, uint32_t *site, uint32_t *site_cur, uint32_t *site_ent,
-                        uint32_t n_panels, unsigned long long *total, hipStream_t stream)
+                        uint4 *site_inl, uint32_t n_panels, unsigned long long *total, hipStream_t stream)
 {
     const unsigned blocks = (unsigned)((set.n + 31) / 32);
     if (fill)
         hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
-                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, n_panels, total);
+                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, reinterpret_cast<uint16_t *>(site_inl), n_panels, total);
     else
         hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
-                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, n_panels, total);
+                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, reinterpret_cast<uint16_t *>(site_inl), n_panels, total);
     return hipGetLastError();
 }
 
@@ -934,11 +1027,12 @@ hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hi
     return hipGetLastError();
 }
 
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, size_t n, hipStream_t stream)
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, uint4 *inl, size_t n, hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cnt, tab, n);
+    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cnt, tab,
+                       reinterpret_cast<uint16_t *>(inl), n);
     return hipGetLastError();
 }
 
@@ -956,7 +1050,13 @@ template <int FAM, bool WIDE, int OUT>
 hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
     constexpr int W = Pack<FAM, WIDE>::W;
-    const size_t smem = ((size_t)2 * kAccRows * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1) * sizeof(uint32_t);
+#ifdef DST_DBG_RB
+    constexpr int RBL = DST_DBG_RB;
+#else
+    constexpr int RBL = kAccRows;
+#endif
+    const size_t smem = ((size_t)2 * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
+                         (aligned_output<FAM, WIDE, OUT>() ? kPanelCols : 0)) * sizeof(uint32_t);
     auto kern = consensus_pair_kernel<FAM, WIDE, OUT>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -965,7 +1065,7 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
             return e;
     }
     hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(256 + 64 * kEventWaves), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
-                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.tab, cl.cols->site.ent,
+                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.inl, cl.cols->site.tab, cl.cols->site.ent,
                        cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
                        (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0, cl.d_hot);

@@ -52,6 +52,7 @@ constexpr uint32_t kEntryShift = 28;       // list entries: nibble in the top fo
 constexpr uint32_t kEntryMask = (1u << kEntryShift) - 1;   // bucket entries: column record | nibble << 28
 constexpr uint32_t kSiteBits = 25;         // record-list entries: site | reference class << 25 | nibble << 28
 constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
+constexpr uint32_t kInlineEvents = 15;     // bucket entries held inside the 32-byte lookup-table entry
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
 constexpr uint32_t kHotPermille = 33;      // hybrid path: a site is "hot" when more than 3.3 % of the sampled records deviate
@@ -82,7 +83,12 @@ struct RecordIndex {              // per record: the sites where it differs from
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
     uint32_t *cnt = nullptr;      // [n_sites * n_panels + 1] entries per bucket
     uint32_t *off = nullptr;      // [n_sites * n_panels + 1] bucket starts: every bucket begins on a 16-byte boundary
-    uint2 *tab = nullptr;         // [n_sites * n_panels] {start, entries}: one 8-byte load per lookup
+    uint2 *tab = nullptr;         // [n_sites * n_panels] {start, entries} of the bucket in `ent`
+    // [n_sites * n_panels] 32 bytes per bucket = 16 halfwords: entries (saturating), then the first kInlineEvents
+    // entries as record-in-panel | nibble << 11.  The pair kernel reads THIS: one request per (row entry, panel)
+    // brings the whole bucket of a typical site; `tab` + `ent` serve the buckets that are larger.
+    uint4 *inl = nullptr;
+    size_t inl_cap = 0;
     uint32_t *ent = nullptr;      // record | nibble << 28 (any order inside a bucket; padding is never read)
     size_t cnt_cap = 0, off_cap = 0, tab_cap = 0, ent_cap = 0;
     uint32_t n_panels = 0;
@@ -186,14 +192,14 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
                         bool skip_nclass,
                         uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_off_or_cnt, uint32_t *site_cur,
-                        uint32_t *site_ent, uint32_t n_panels, unsigned long long *total, hipStream_t stream);
+                        uint32_t *site_ent, uint4 *site_inl, uint32_t n_panels, unsigned long long *total, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
 // bucket sizes -> sizes rounded up to 4 entries (scanned next); scanned starts + sizes -> the lookup table
 hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hipStream_t stream);
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, size_t n, hipStream_t stream);
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, uint4 *inl, size_t n, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
                                   hipStream_t stream);
