@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 void free_set(DeviceSet &s)
 {
     void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent,
-                    s.site.cnt, s.site.off, s.site.tab, s.site.inl, s.site.ent, s.aconst};
+                    s.site.cnt, s.site.off, s.site.tab, s.site.inl, s.site.ovf, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -252,7 +252,7 @@ int ensure_lut(dst_ctx *ctx)
     build_consensus_lut(*lut);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_lut, sizeof(ConsensusLut)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lut, lut.get(), sizeof(ConsensusLut), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_total, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_total, 2 * sizeof(unsigned long long)));  // [0] list entries, [1] overflow entries
     return DST_OK;
 }
 
@@ -373,6 +373,9 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         return rc;
     const uint32_t n_panels = (uint32_t)((s.n + kPanelCols - 1) / kPanelCols);
     const size_t n_buckets = want_sites ? s.nchunks * kChunkSites * (size_t)n_panels : 0;
+    // 32 bytes of lookup table per (site, panel); bucket numbers travel as 32-bit values
+    if (n_buckets >= 0xFFFFFFFFull || n_buckets * 2 * sizeof(uint4) > (16ull << 30))
+        return fail(ctx, DST_ERR_CAPACITY, "too many sites x panels for the consensus path's lookup table");
     rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.cnt, &s.site.cnt_cap, (n_buckets + 1) * sizeof(uint32_t));
@@ -382,8 +385,6 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         rc = ensure_bytes(ctx, (void **)&s.site.tab, &s.site.tab_cap, std::max<size_t>(n_buckets, 1) * sizeof(uint2));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.inl, &s.site.inl_cap, std::max<size_t>(n_buckets, 1) * 2 * sizeof(uint4));
-    if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&ctx->site_cur, &ctx->site_cur_bytes, (n_buckets + 1) * sizeof(uint32_t));
     if (!rc)
         rc = ensure_bytes(ctx, (void **)&ctx->scan_tmp, &ctx->scan_tmp_bytes,
                           scan_tmp_words(std::max(s.n + 1, n_buckets + 1)) * sizeof(uint32_t));
@@ -391,35 +392,39 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         return rc;
     s.rec.valid = false;
     s.site.valid = false;
+    uint32_t *d_ovf_n = reinterpret_cast<uint32_t *>(ctx->d_total + 1);
     HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
-    if (want_sites)
-        HIP_TRY(ctx, hipMemsetAsync(s.site.cnt, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, want_sites, false, s.rec.off, nullptr, s.site.cnt, nullptr,
-                              nullptr, nullptr, n_panels, ctx->d_total, stream));
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, false, s.rec.off, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, ctx->d_total, stream));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (total > kMaxListEntries / 4)
         return fail(ctx, DST_ERR_CAPACITY, "too many differences from the reference sequence for the consensus path");
     s.rec.total = total;
-    // buckets start on 16-byte boundaries: at most 3 entries of padding per non-empty bucket
-    const size_t padded_cap = (size_t)total + 3 * std::min<size_t>(total, n_buckets) + 4;
-    rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, std::max<size_t>(total, 1) * sizeof(uint32_t));
+    const size_t cap = std::max<size_t>(total, 1);
+    rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, cap * sizeof(uint32_t));
     if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, padded_cap * sizeof(uint32_t));
+        rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, cap * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.site.ovf, &s.site.ovf_cap, cap * sizeof(uint2));
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
+    if (want_sites)
+        HIP_TRY(ctx, hipMemsetAsync(s.site.cnt, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.cnt,
+                              s.site.inl, s.site.ovf, d_ovf_n, ctx->d_total, stream));
     if (want_sites) {
-        HIP_TRY(ctx, launch_pad_counts(s.site.cnt, s.site.off, n_buckets, stream));
+        // the cursors are the bucket sizes now: sizes into the table entries, the entries beyond the inline ones
+        // (rare: a bucket holds more than kInlineEvents records of a 2,048-record panel) into bucket order
+        HIP_TRY(ctx, launch_site_sizes(s.site.cnt, s.site.inl, s.site.off, n_buckets, stream));
         HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
-        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, s.site.inl, n_buckets, stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->site_cur, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
+        HIP_TRY(ctx, launch_ovf_place(s.site.ovf, d_ovf_n, s.site.off, s.site.cnt, s.site.ent, stream));
     }
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.off,
-                              ctx->site_cur, s.site.ent, want_sites ? s.site.inl : nullptr, n_panels, ctx->d_total, stream));
     // runs queued on other streams wait for this on the device
     rc = publish_prep(ctx, stream);
     if (rc)
@@ -863,7 +868,7 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
-    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, (void *)ctx->site_cur, ctx->host_out, ctx->hot_tally})
+    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, ctx->host_out, ctx->hot_tally})
         if (b)
             (void)hipFree(b);
     if (ctx->scratch)
@@ -1096,7 +1101,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e == hipSuccess)
         e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
@@ -1124,7 +1129,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
         return done(DST_OK);
     e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, nullptr, 1, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, nullptr, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

@@ -219,19 +219,19 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
 // One wave = 8 records x 8 chunks per step (lane = chunk-lane * 8 + record-lane), so the eight lanes of
 // a chunk read one 128-byte line of each plane, and a record's entries come out in ascending site order:
 // the exclusive prefix over the chunk-lanes of a record is three shuffles.
-// FILL == false: rec[r] = list length, site[b] += 1 per entry (b = (r / kPanelCols) * sites + site, sites = nchunks * 128:
-// panel-major, so everything one panel's tiles look up is one contiguous, L2-sized piece).
-// FILL == true : rec = scanned offsets, site = scanned bucket offsets, site_cur = zeroed cursors.
+// FILL == false: rec[r] = list length.
+// FILL == true : rec = scanned offsets; want_sites: the entry also goes into its bucket b = (r / kPanelCols) * sites + site
+// (sites = nchunks * 128: panel-major, so everything one panel's tiles look up is one contiguous, L2-sized piece);
+// site_cur = zeroed cursors (the bucket sizes afterwards).
 template <bool FILL>
 __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ planes,
                                                     const uint4 *__restrict__ ref_planes,
                                                     const uint4 *__restrict__ hot_planes, uint32_t n,
                                                     uint32_t nchunks, uint32_t npad, int want_sites,
                                                     int skip_nclass, uint32_t *__restrict__ rec,
-                                                    uint32_t *__restrict__ rec_ent, uint32_t *__restrict__ site,
-                                                    uint32_t *__restrict__ site_cur,
-                                                    uint32_t *__restrict__ site_ent, uint16_t *__restrict__ site_inl,
-                                                    uint32_t n_panels, unsigned long long *__restrict__ total)
+                                                    uint32_t *__restrict__ rec_ent, uint32_t *__restrict__ site_cur,
+                                                    uint16_t *__restrict__ site_inl, uint2 *__restrict__ site_ovf,
+                                                    uint32_t *__restrict__ ovf_n, unsigned long long *__restrict__ total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t rl = lane & 7u, cl = lane >> 3;
@@ -302,14 +302,15 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                               ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
                         rec_ent[at++] = s | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
                         if (want_sites) {
-                            const size_t bk = (size_t)panel * ((size_t)nchunks * kChunkSites) + s;
+                            // the bucket of (panel, site): its first kInlineEvents entries live in the 32-byte
+                            // lookup-table entry itself, later ones go to the overflow list (placed by ovf_place_kernel)
+                            const uint32_t bk = panel * (nchunks * kChunkSites) + s;
                             const uint32_t pos = atomicAdd(&site_cur[bk], 1u);
-                            site_ent[site[bk] + pos] = r | nib << kEntryShift;
-                            if (pos < kInlineEvents)   // the lookup-table entry itself holds the first entries
-                                site_inl[bk * 16 + 1 + pos] = (uint16_t)((r & (kPanelCols - 1u)) | nib << 11);
+                            if (pos < kInlineEvents)
+                                site_inl[(size_t)bk * 16 + 1 + pos] = (uint16_t)((r & (kPanelCols - 1u)) | nib << 11);
+                            else
+                                site_ovf[atomicAdd(ovf_n, 1u)] = make_uint2(bk, r | nib << kEntryShift);
                         }
-                    } else if (want_sites) {
-                        atomicAdd(&site[(size_t)panel * ((size_t)nchunks * kChunkSites) + s], 1u);
                     }
                 }
             }
@@ -379,23 +380,40 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
             data[base + k] += off;
 }
 
-__global__ __launch_bounds__(256) void pad_counts_kernel(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ padded,
-                                                          size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
-        padded[i] = (cnt[i] + 3u) & ~3u;
-    else if (i == n)
-        padded[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void site_table_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt,
-                                                          uint2 *__restrict__ tab, uint16_t *__restrict__ inl, size_t n)
+// bucket sizes (the fill pass's cursors) -> halfword 0 of the 32-byte table entries, and the number of entries
+// beyond the inline ones (scanned next: their places in the overflow array)
+__global__ __launch_bounds__(256) void site_sizes_kernel(const uint32_t *__restrict__ cur, uint16_t *__restrict__ inl,
+                                                          uint32_t *__restrict__ ovf_cnt, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        tab[i] = make_uint2(off[i], cnt[i]);
-        inl[i * 16] = (uint16_t)min(cnt[i], 0xFFFFu);   // halfword 0 of the 32-byte entry; the fill pass writes 1..15
+        const uint32_t c = cur[i];
+        inl[i * 16] = (uint16_t)min(c, 0xFFFFu);
+        ovf_cnt[i] = c > kInlineEvents ? c - kInlineEvents : 0u;
+    } else if (i == n) {
+        ovf_cnt[i] = 0;
+    }
+}
+
+// {start of the bucket's overflow entries, bucket size}: read only for buckets larger than kInlineEvents
+__global__ __launch_bounds__(256) void site_table_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cur,
+                                                          uint2 *__restrict__ tab, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        tab[i] = make_uint2(off[i], cur[i]);
+}
+
+// the overflow list (any order) -> bucket order.  The cursors count down: afterwards cur[b] <= kInlineEvents.
+__global__ __launch_bounds__(256) void ovf_place_kernel(const uint2 *__restrict__ ovf, const uint32_t *__restrict__ ovf_n,
+                                                         const uint32_t *__restrict__ off, uint32_t *__restrict__ cur,
+                                                         uint32_t *__restrict__ site_ent)
+{
+    const uint32_t total = *ovf_n;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint2 e = ovf[i];
+        const uint32_t p = atomicSub(&cur[e.x], 1u) - 1u - kInlineEvents;
+        site_ent[off[e.x] + p] = e.y;
     }
 }
 
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
             uint32_t o0 = 0, ex = 0;
             if (cnt > kInlineEvents) {
                 const uint2 tab = site_tab[(size_t)tile.panel * n_sites + t.site];
-                o0 = tab.x + kInlineEvents;
+                o0 = tab.x;   // the entries beyond the inline ones, in the overflow array
                 ex = tab.y - kInlineEvents;
             }
             uint32_t incl = ex, up;
@@ -979,19 +997,19 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 }
 
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
-                        bool skip_nclass,
-                        uint32_t *rec, uint32_t *rec_ent, uint32_t *site, uint32_t *site_cur, uint32_t *site_ent,
-                        uint4 *site_inl, uint32_t n_panels, unsigned long long *total, hipStream_t stream)
+                        bool skip_nclass, uint32_t *rec, uint32_t *rec_ent, uint32_t *site_cur, uint4 *site_inl,
+                        uint2 *site_ovf, uint32_t *ovf_n, unsigned long long *total, hipStream_t stream)
 {
     const unsigned blocks = (unsigned)((set.n + 31) / 32);
     if (fill)
         hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
-                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, reinterpret_cast<uint16_t *>(site_inl), n_panels, total);
+                           skip_nclass ? 1 : 0, rec, rec_ent, site_cur, reinterpret_cast<uint16_t *>(site_inl), site_ovf,
+                           ovf_n, total);
     else
         hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
-                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
-                           skip_nclass ? 1 : 0, rec, rec_ent, site, site_cur, site_ent, reinterpret_cast<uint16_t *>(site_inl), n_panels, total);
+                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, 0, skip_nclass ? 1 : 0, rec,
+                           rec_ent, site_cur, reinterpret_cast<uint16_t *>(site_inl), site_ovf, ovf_n, total);
     return hipGetLastError();
 }
 
@@ -1021,18 +1039,25 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hipStream_t stream)
+hipError_t launch_site_sizes(const uint32_t *cur, uint4 *inl, uint32_t *ovf_cnt, size_t n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pad_counts_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, cnt, padded, n);
+    hipLaunchKernelGGL(site_sizes_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, cur,
+                       reinterpret_cast<uint16_t *>(inl), ovf_cnt, n);
     return hipGetLastError();
 }
 
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, uint4 *inl, size_t n, hipStream_t stream)
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cur, uint2 *tab, size_t n, hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cnt, tab,
-                       reinterpret_cast<uint16_t *>(inl), n);
+    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cur, tab, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ovf_place(const uint2 *ovf, const uint32_t *ovf_n, const uint32_t *off, uint32_t *cur, uint32_t *site_ent,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(ovf_place_kernel, dim3(512), dim3(256), 0, stream, ovf, ovf_n, off, cur, site_ent);
     return hipGetLastError();
 }
 

@@ -37,8 +37,6 @@ struct dst_ctx {
     unsigned long long *d_total = nullptr;
     uint32_t *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
-    uint32_t *site_cur = nullptr;
-    size_t site_cur_bytes = 0;
     void *hot_tally = nullptr;  // hybrid path: the dense kernels' tallies of the hot columns (grow-only)
     size_t hot_tally_bytes = 0;
     hipEvent_t hot_free = nullptr;  // recorded after the last reader of `hot_tally`

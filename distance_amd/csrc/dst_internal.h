@@ -81,15 +81,17 @@ struct RecordIndex {              // per record: the sites where it differs from
 };
 
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
-    uint32_t *cnt = nullptr;      // [n_sites * n_panels + 1] entries per bucket
-    uint32_t *off = nullptr;      // [n_sites * n_panels + 1] bucket starts: every bucket begins on a 16-byte boundary
-    uint2 *tab = nullptr;         // [n_sites * n_panels] {start, entries} of the bucket in `ent`
+    uint32_t *cnt = nullptr;      // [n_sites * n_panels + 1] fill cursors = entries per bucket
+    uint32_t *off = nullptr;      // [n_sites * n_panels + 1] start of the bucket's overflow entries in `ent`
+    uint2 *tab = nullptr;         // [n_sites * n_panels] {overflow start, entries}
+    uint2 *ovf = nullptr;         // {bucket, entry} of the entries beyond the inline ones, in the order they were found
+    size_t ovf_cap = 0;
     // [n_sites * n_panels] 32 bytes per bucket = 16 halfwords: entries (saturating), then the first kInlineEvents
     // entries as record-in-panel | nibble << 11.  The pair kernel reads THIS: one request per (row entry, panel)
     // brings the whole bucket of a typical site; `tab` + `ent` serve the buckets that are larger.
     uint4 *inl = nullptr;
     size_t inl_cap = 0;
-    uint32_t *ent = nullptr;      // record | nibble << 28 (any order inside a bucket; padding is never read)
+    uint32_t *ent = nullptr;      // overflow entries by bucket: record | nibble << 28 (any order inside a bucket)
     size_t cnt_cap = 0, off_cap = 0, tab_cap = 0, ent_cap = 0;
     uint32_t n_panels = 0;
     bool valid = false;
@@ -190,16 +192,18 @@ hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint32_t n_hot, DeviceSet &dst, hipStream_t stream);
 // hot_planes != NULL: sites whose bit is set are left out of the lists
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
-                        bool skip_nclass,
-                        uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_off_or_cnt, uint32_t *site_cur,
-                        uint32_t *site_ent, uint4 *site_inl, uint32_t n_panels, unsigned long long *total, hipStream_t stream);
+                        bool skip_nclass, uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_cur, uint4 *site_inl,
+                        uint2 *site_ovf, uint32_t *ovf_n, unsigned long long *total, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
-// bucket sizes -> sizes rounded up to 4 entries (scanned next); scanned starts + sizes -> the lookup table
-hipError_t launch_pad_counts(const uint32_t *cnt, uint32_t *padded, size_t n, hipStream_t stream);
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cnt, uint2 *tab, uint4 *inl, size_t n, hipStream_t stream);
+// after the fill pass: bucket sizes -> table entries + overflow counts (scanned next), {overflow start, size}
+// per bucket, and the overflow list into bucket order
+hipError_t launch_site_sizes(const uint32_t *cur, uint4 *inl, uint32_t *ovf_cnt, size_t n, hipStream_t stream);
+hipError_t launch_site_table(const uint32_t *off, const uint32_t *cur, uint2 *tab, size_t n, hipStream_t stream);
+hipError_t launch_ovf_place(const uint2 *ovf, const uint32_t *ovf_n, const uint32_t *off, uint32_t *cur, uint32_t *site_ent,
+                            hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
                                   hipStream_t stream);
