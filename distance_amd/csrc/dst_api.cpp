@@ -51,7 +51,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent, s.rec.col,
                     s.site.cnt, s.site.off, s.site.tab, s.site.inl, s.site.ovf, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -396,8 +396,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, false, s.rec.off, nullptr, nullptr, nullptr,
-                              nullptr, nullptr, ctx->d_total, stream));
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, nullptr, ctx->d_total, stream));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -405,7 +404,9 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         return fail(ctx, DST_ERR_CAPACITY, "too many differences from the reference sequence for the consensus path");
     s.rec.total = total;
     const size_t cap = std::max<size_t>(total, 1);
-    rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, cap * sizeof(uint32_t));
+    rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, (cap + 4) * sizeof(uint32_t));  // 16-byte reads past the end
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.rec.col, &s.rec.col_cap, (cap + 4) * sizeof(uint16_t));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, cap * sizeof(uint32_t));
     if (!rc && want_sites)
@@ -413,14 +414,13 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
-    if (want_sites)
-        HIP_TRY(ctx, hipMemsetAsync(s.site.cnt, 0, (n_buckets + 1) * sizeof(uint32_t), stream));
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, want_sites, false, s.rec.off, s.rec.ent, s.site.cnt,
-                              s.site.inl, s.site.ovf, d_ovf_n, ctx->d_total, stream));
+    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent, want_sites ? s.rec.col : nullptr,
+                              ctx->d_total, stream));
     if (want_sites) {
-        // the cursors are the bucket sizes now: sizes into the table entries, the entries beyond the inline ones
-        // (rare: a bucket holds more than kInlineEvents records of a 2,048-record panel) into bucket order
-        HIP_TRY(ctx, launch_site_sizes(s.site.cnt, s.site.inl, s.site.off, n_buckets, stream));
+        // the buckets from the lists; then the entries beyond the inline ones (rare: a bucket holds more than
+        // kInlineEvents records of a 2,048-record panel) into bucket order
+        HIP_TRY(ctx, launch_site_buckets(s, n_panels, d_ovf_n, stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.site.off + n_buckets, 0, sizeof(uint32_t), stream));
         HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
         HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
         HIP_TRY(ctx, launch_ovf_place(s.site.ovf, d_ovf_n, s.site.off, s.site.cnt, s.site.ent, stream));
@@ -1101,7 +1101,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e == hipSuccess)
         e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, false, false, true, d_off, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, false, true, d_off, nullptr, nullptr, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
@@ -1129,7 +1129,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
         return done(DST_OK);
     e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, true, false, true, d_off, d_ent, nullptr, nullptr, nullptr, nullptr, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, true, true, d_off, d_ent, nullptr, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

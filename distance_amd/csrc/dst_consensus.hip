@@ -60,17 +60,32 @@ __global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restr
     const uint32_t w = b >> 5, bit = b & 31;
     const size_t ps = (size_t)nchunks * npad * 4;  // plane stride in 32-bit words
     uint32_t cnt[5] = {0, 0, 0, 0, 0};
-    for (uint32_t k = grp; k < samples; k += 4) {
-        const uint32_t r = (uint32_t)(((uint64_t)k * n) / samples);
-        const size_t at = ((size_t)c * npad + r) * 4 + w;
-        const uint32_t A = (planes32[PL_A * ps + at] >> bit) & 1u, G = (planes32[PL_G * ps + at] >> bit) & 1u;
-        const uint32_t C = (planes32[PL_C * ps + at] >> bit) & 1u, T = (planes32[PL_T * ps + at] >> bit) & 1u;
-        const uint32_t nib = A << 3 | G << 2 | C << 1 | T;
-        cnt[0] += nib == 8;
-        cnt[1] += nib == 4;
-        cnt[2] += nib == 2;
-        cnt[3] += nib == 1;
-        cnt[4] += nib == 15;
+    // 8 sampled records per round: their 32 loads are issued together (one record at a time this kernel was a chain
+    // of 128 memory latencies on one block per CU: 0.12 ms for 8 MB)
+    for (uint32_t k0 = grp; k0 < samples; k0 += 32) {
+        uint32_t pw[8][4];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t k = k0 + 4 * u;
+            const uint32_t r = (uint32_t)(((uint64_t)min(k, samples - 1) * n) / samples);
+            const size_t at = ((size_t)c * npad + r) * 4 + w;
+            pw[u][0] = planes32[PL_A * ps + at];
+            pw[u][1] = planes32[PL_G * ps + at];
+            pw[u][2] = planes32[PL_C * ps + at];
+            pw[u][3] = planes32[PL_T * ps + at];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            if (k0 + 4 * u >= samples)
+                break;
+            const uint32_t nib = ((pw[u][0] >> bit) & 1u) << 3 | ((pw[u][1] >> bit) & 1u) << 2 |
+                                 ((pw[u][2] >> bit) & 1u) << 1 | ((pw[u][3] >> bit) & 1u);
+            cnt[0] += nib == 8;
+            cnt[1] += nib == 4;
+            cnt[2] += nib == 2;
+            cnt[3] += nib == 1;
+            cnt[4] += nib == 15;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k)
@@ -219,26 +234,21 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
 // One wave = 8 records x 8 chunks per step (lane = chunk-lane * 8 + record-lane), so the eight lanes of
 // a chunk read one 128-byte line of each plane, and a record's entries come out in ascending site order:
 // the exclusive prefix over the chunk-lanes of a record is three shuffles.
-// FILL == false: rec[r] = list length.
-// FILL == true : rec = scanned offsets; want_sites: the entry also goes into its bucket b = (r / kPanelCols) * sites + site
-// (sites = nchunks * 128: panel-major, so everything one panel's tiles look up is one contiguous, L2-sized piece);
-// site_cur = zeroed cursors (the bucket sizes afterwards).
+// FILL == false: rec[r] = list length.   FILL == true: rec = scanned offsets, entries written in ascending site order.
+// (A column set's lists and buckets are filled together by site_fill_kernel below instead.)
 template <bool FILL>
 __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ planes,
                                                     const uint4 *__restrict__ ref_planes,
                                                     const uint4 *__restrict__ hot_planes, uint32_t n,
-                                                    uint32_t nchunks, uint32_t npad, int want_sites,
-                                                    int skip_nclass, uint32_t *__restrict__ rec,
-                                                    uint32_t *__restrict__ rec_ent, uint32_t *__restrict__ site_cur,
-                                                    uint16_t *__restrict__ site_inl, uint2 *__restrict__ site_ovf,
-                                                    uint32_t *__restrict__ ovf_n, unsigned long long *__restrict__ total)
+                                                    uint32_t nchunks, uint32_t npad, int skip_nclass,
+                                                    uint32_t *__restrict__ rec, uint32_t *__restrict__ rec_ent,
+                                                    uint16_t *__restrict__ rec_col, unsigned long long *__restrict__ total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t rl = lane & 7u, cl = lane >> 3;
     const uint32_t r = wave * 8u + rl;
     const bool live = r < n;
     const size_t ps = (size_t)nchunks * npad;
-    const uint32_t panel = r / kPanelCols;
     uint32_t run = 0;
     const uint32_t base0 = (FILL && live) ? rec[r] : 0u;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
@@ -300,17 +310,9 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                              ((cw[w] >> bit) & 1u) << 1 | ((tw[w] >> bit) & 1u);
                         const uint32_t rnib = ((raw[w] >> bit) & 1u) << 3 | ((rgw[w] >> bit) & 1u) << 2 |
                                               ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
+                        if (rec_col)   // a column set: the entry's record within its panel, for site_bucket_kernel
+                            rec_col[at] = (uint16_t)(r & (kPanelCols - 1u));
                         rec_ent[at++] = s | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
-                        if (want_sites) {
-                            // the bucket of (panel, site): its first kInlineEvents entries live in the 32-byte
-                            // lookup-table entry itself, later ones go to the overflow list (placed by ovf_place_kernel)
-                            const uint32_t bk = panel * (nchunks * kChunkSites) + s;
-                            const uint32_t pos = atomicAdd(&site_cur[bk], 1u);
-                            if (pos < kInlineEvents)
-                                site_inl[(size_t)bk * 16 + 1 + pos] = (uint16_t)((r & (kPanelCols - 1u)) | nib << 11);
-                            else
-                                site_ovf[atomicAdd(ovf_n, 1u)] = make_uint2(bk, r | nib << kEntryShift);
-                        }
                     }
                 }
             }
@@ -328,6 +330,80 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
         if (lane == 0 && sum)
             atomicAdd(total, (unsigned long long)sum);
     }
+}
+
+// =============================================================================================
+// site buckets of a column set, from its difference lists
+// =============================================================================================
+// One block = one (panel of 2,048 records, range of kBucketSites sites): it owns the buckets of that piece, so
+// their sizes are LDS counters and their 32-byte lookup-table entries are assembled in LDS and leave as one
+// contiguous 32 KB piece — no global atomics, no scattered 2-byte writes into the table.  The block streams ALL
+// list entries of the panel's records (16-byte loads; the lists are 1/250 of the planes they were made from) and
+// keeps the ones of its sites; the record of an entry travels beside it (rec_col).  Entries beyond kInlineEvents
+// per bucket go to the overflow list.
+constexpr uint32_t kBucketSites = 1024;
+
+constexpr uint32_t kBucketThreads = 1024;
+
+__global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint32_t *__restrict__ rec_off,
+                                                          const uint32_t *__restrict__ rec_ent,
+                                                          const uint16_t *__restrict__ rec_col, uint32_t n,
+                                                          uint32_t n_sites, uint4 *__restrict__ site_inl,
+                                                          uint32_t *__restrict__ site_cnt, uint32_t *__restrict__ ovf_cnt,
+                                                          uint2 *__restrict__ site_ovf, uint32_t *__restrict__ ovf_n)
+{
+    constexpr uint32_t NT = kBucketThreads, UNROLL = 4;
+    __shared__ uint32_t cnt[kBucketSites];
+    __shared__ __attribute__((aligned(16))) uint16_t tabl[kBucketSites][16];
+    const uint32_t panel = blockIdx.y, tid = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * kBucketSites, ns = min(kBucketSites, n_sites - s0);
+    const uint32_t r0 = panel * kPanelCols, nrec = min(kPanelCols, n - r0);
+    for (uint32_t k = tid; k < kBucketSites; k += NT)
+        cnt[k] = 0;
+    for (uint32_t k = tid; k < kBucketSites * 2; k += NT)
+        reinterpret_cast<uint4 *>(&tabl[0][0])[k] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t e0 = rec_off[r0], e1 = rec_off[r0 + nrec];
+    const uint32_t bucket0 = panel * n_sites + s0;
+    // UNROLL 16-byte loads in flight per thread (one at a time the loop is a chain of memory latencies)
+    for (uint32_t ib = (e0 & ~3u) + 4u * tid; ib < e1; ib += 4u * NT * UNROLL) {
+        uint4 v[UNROLL];
+        uint2 vc[UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < UNROLL; ++u) {
+            const uint32_t i = ib + u * 4u * NT;   // (both arrays have 4 entries of slack at their ends)
+            v[u] = i < e1 ? *reinterpret_cast<const uint4 *>(rec_ent + i) : make_uint4(0, 0, 0, 0);
+            vc[u] = i < e1 ? *reinterpret_cast<const uint2 *>(rec_col + i) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UNROLL; ++u) {
+            const uint32_t i = ib + u * 4u * NT;
+            const uint32_t ev[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const uint32_t cv[4] = {vc[u].x & 0xFFFFu, vc[u].x >> 16, vc[u].y & 0xFFFFu, vc[u].y >> 16};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t idx = i + j, sl = (ev[j] & kSiteMask) - s0;
+                if (idx < e0 || idx >= e1 || sl >= ns)
+                    continue;
+                const uint32_t lo = cv[j], nib = ev[j] >> kEntryShift;
+                const uint32_t pos = atomicAdd(&cnt[sl], 1u);
+                if (pos < kInlineEvents)
+                    tabl[sl][1 + pos] = (uint16_t)(lo | nib << 11);
+                else
+                    site_ovf[atomicAdd(ovf_n, 1u)] = make_uint2(bucket0 + sl, (r0 + lo) | nib << kEntryShift);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < ns; k += NT) {
+        const uint32_t c = cnt[k];
+        tabl[k][0] = (uint16_t)min(c, 0xFFFFu);
+        site_cnt[bucket0 + k] = c;
+        ovf_cnt[bucket0 + k] = c > kInlineEvents ? c - kInlineEvents : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < ns * 2; k += NT)
+        site_inl[(size_t)bucket0 * 2 + k] = reinterpret_cast<const uint4 *>(&tabl[0][0])[k];
 }
 
 // =============================================================================================
@@ -378,21 +454,6 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
     for (int k = 0; k < 8; ++k)
         if (base + k < n)
             data[base + k] += off;
-}
-
-// bucket sizes (the fill pass's cursors) -> halfword 0 of the 32-byte table entries, and the number of entries
-// beyond the inline ones (scanned next: their places in the overflow array)
-__global__ __launch_bounds__(256) void site_sizes_kernel(const uint32_t *__restrict__ cur, uint16_t *__restrict__ inl,
-                                                          uint32_t *__restrict__ ovf_cnt, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const uint32_t c = cur[i];
-        inl[i * 16] = (uint16_t)min(c, 0xFFFFu);
-        ovf_cnt[i] = c > kInlineEvents ? c - kInlineEvents : 0u;
-    } else if (i == n) {
-        ovf_cnt[i] = 0;
-    }
 }
 
 // {start of the bucket's overflow entries, bucket size}: read only for buckets larger than kInlineEvents
@@ -996,20 +1057,25 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
-                        bool skip_nclass, uint32_t *rec, uint32_t *rec_ent, uint32_t *site_cur, uint4 *site_inl,
-                        uint2 *site_ovf, uint32_t *ovf_n, unsigned long long *total, hipStream_t stream)
+hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
+                        uint32_t *rec, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total, hipStream_t stream)
 {
     const unsigned blocks = (unsigned)((set.n + 31) / 32);
     if (fill)
         hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
-                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, want_sites ? 1 : 0,
-                           skip_nclass ? 1 : 0, rec, rec_ent, site_cur, reinterpret_cast<uint16_t *>(site_inl), site_ovf,
-                           ovf_n, total);
+                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, rec_col, total);
     else
         hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
-                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, 0, skip_nclass ? 1 : 0, rec,
-                           rec_ent, site_cur, reinterpret_cast<uint16_t *>(site_inl), site_ovf, ovf_n, total);
+                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, rec_col, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_n, hipStream_t stream)
+{
+    const uint32_t n_sites = (uint32_t)(set.nchunks * kChunkSites);
+    hipLaunchKernelGGL(site_bucket_kernel, dim3((n_sites + kBucketSites - 1) / kBucketSites, n_panels), dim3(kBucketThreads), 0, stream,
+                       set.rec.off, set.rec.ent, set.rec.col, (uint32_t)set.n, n_sites, set.site.inl, set.site.cnt, set.site.off,
+                       set.site.ovf, ovf_n);
     return hipGetLastError();
 }
 
@@ -1036,13 +1102,6 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, stream, data, n, tmp);
-    return hipGetLastError();
-}
-
-hipError_t launch_site_sizes(const uint32_t *cur, uint4 *inl, uint32_t *ovf_cnt, size_t n, hipStream_t stream)
-{
-    hipLaunchKernelGGL(site_sizes_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, cur,
-                       reinterpret_cast<uint16_t *>(inl), ovf_cnt, n);
     return hipGetLastError();
 }
 

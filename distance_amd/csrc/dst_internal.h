@@ -72,7 +72,8 @@ struct ConsensusRef {             // the reference sequence, sampled from the se
 struct RecordIndex {              // per record: the sites where it differs from the reference, ascending
     uint32_t *off = nullptr;      // [n + 1]
     uint32_t *ent = nullptr;      // site | class of the reference there << 25 | the record's nibble << 28
-    size_t off_cap = 0, ent_cap = 0;
+    uint16_t *col = nullptr;      // column sets: the entry's record within its panel (read by site_bucket_kernel)
+    size_t off_cap = 0, ent_cap = 0, col_cap = 0;
     uint64_t total = 0;
     const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
     uint64_t ref_epoch = 0;
@@ -191,16 +192,17 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint32_t n_hot, DeviceSet &dst, hipStream_t stream);
 // hot_planes != NULL: sites whose bit is set are left out of the lists
-hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool want_sites,
-                        bool skip_nclass, uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint32_t *site_cur, uint4 *site_inl,
-                        uint2 *site_ovf, uint32_t *ovf_n, unsigned long long *total, hipStream_t stream);
+hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
+                        uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total,
+                        hipStream_t stream);
+// a column set's site buckets from its lists (set.rec -> set.site: 32-byte table entries, sizes, overflow counts + list)
+hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_n, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
 // after the fill pass: bucket sizes -> table entries + overflow counts (scanned next), {overflow start, size}
 // per bucket, and the overflow list into bucket order
-hipError_t launch_site_sizes(const uint32_t *cur, uint4 *inl, uint32_t *ovf_cnt, size_t n, hipStream_t stream);
 hipError_t launch_site_table(const uint32_t *off, const uint32_t *cur, uint2 *tab, size_t n, hipStream_t stream);
 hipError_t launch_ovf_place(const uint2 *ovf, const uint32_t *ovf_n, const uint32_t *off, uint32_t *cur, uint32_t *site_ent,
                             hipStream_t stream);
