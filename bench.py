@@ -6,7 +6,8 @@
 
 One "step" = one pass of the hot path over the whole synthetic alignment, starting from the row-major
 N x L Paradis byte matrix resident in HBM: bit-plane pack -> (difference lists) -> pair kernel -> f64
-distances in canonical order in HBM (-> for N>1, every rank's slab sent straight to rank 0 over RCCL).
+distances in canonical order in HBM.  N>1: every rank computes a contiguous range of the canonical order into its own
+HBM (--exchange gather: and sends it straight to rank 0 over RCCL).
 Prints ONE JSON line (rank 0).  `value` = pairs of the whole job / step time, on the library's default
 path choice (DST_PATH_AUTO); the line also carries, each timed over the same steps/warmup:
   legs.dense      the same measure with the dense bit-plane kernels forced (VALU-issue roofline),
@@ -39,6 +40,8 @@ from tools import synth
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate 6290
 HBM_COPY_GBS = 6290.0
+HBM_FILL_GBS = 4900.0        # write-only kernels: plain 128-byte-aligned 16-B/lane fill of 10 GB, 4.65-5.12 TB/s across boxes
+                             # (tools/ubench/store_rate.hip, profiles/r02/ubench_store_rate.txt)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes x clock
 
 WORKLOADS = {
@@ -144,7 +147,11 @@ def main():
     ap.add_argument("--measure", default="", help="override measure")
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "consensus"], help="kernel path of the main leg")
     ap.add_argument("--variant", type=int, default=0, help="dense pair-kernel tile variant")
-    ap.add_argument("--chunks", type=int, default=8, help="N>1: sub-slabs per rank (send k overlaps compute k+1)")
+    ap.add_argument("--exchange", default="none", choices=["none", "gather"],
+                    help="N>1: 'none' (default) every rank keeps its slab of the result in its own HBM, as the CLI consumes "
+                         "it (one D2H stream per GPU) - no collective in the data path; 'gather': every slab is sent to "
+                         "rank 0 over RCCL send/recv (the north-star's exchange step, xGMI-ingest-bound)")
+    ap.add_argument("--chunks", type=int, default=8, help="N>1 gather: sub-slabs per rank (send k overlaps compute k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra timed legs (dense path, tn93)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=synth.SEED)
@@ -268,6 +275,7 @@ def main():
                    "frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "kernel_ms": k_ms,
                    "algorithmic_bytes_per_launch": nbytes,
                    "frac_of_measured_copy_rate": nbytes / (k_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                   "frac_of_measured_fill_rate": nbytes / (k_ms * 1e-3) / 1e9 / HBM_FILL_GBS,
                    "note": "algorithmic bytes = 8 B of result per pair written once + per-record constants and difference "
                            "lists read once (DESIGN.md 3); the kernel's floor is the HBM write of the N^2/2 results"}
             # the f64 finalisation fused into the output phase (reference operation order): f64 VALU instructions per
@@ -337,7 +345,86 @@ def main():
         return
 
     # ---------------------------------------------------------------------------------------------
-    # N > 1: contiguous canonical ranges, sub-slabs sent to rank 0 while the next one is computed
+    # N > 1, default: contiguous canonical ranges of equal pair count, every rank's slab stays in its own HBM
+    # ---------------------------------------------------------------------------------------------
+    # The path shards with no exchange: a rank needs the packed set (replicated: every rank packs and indexes it) and
+    # writes a contiguous range of the canonical order.  That is how the CLI runs N GPUs (one context, one D2H stream
+    # and one formatter pipeline per GPU; the ordered writer takes the slabs in rank order).
+    if args.exchange == "none":
+        bounds, offsets = slab_layout(n, world, square=True)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        my_pairs = offsets[rank + 1] - offsets[rank]
+        local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+
+        def step():
+            eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+            if my_pairs:
+                eng.run_square_device(measure, r0, r1, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        pair_ms, pack_ms = [], []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            ms = eng.last_kernel_ms()
+            pair_ms.append(ms["pair_ms"])
+            pack_ms.append(ms["pack_ms"])
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        used = eng.last_path()
+        # every rank checks rows of ITS slab against a fresh single-engine dense run; the counts meet on rank 0
+        rows = sorted({r for r in (r0, (r0 + r1) // 2, r1 - 1) if r0 <= r < min(r1, n - 1)})
+        check = verify_rows(eng, codes, local_out, n, L, measure, rows, dev_index, stream, first_row=r0) if rows else \
+            {"rows_checked": 0, "rows_bad": 0}
+        v = torch.tensor([check["rows_checked"], check["rows_bad"]], dtype=torch.int64, device=dev if not args.rehearse_gloo else "cpu")
+        dist.all_reduce(v)
+        if rank == 0:
+            k_ms = float(np.mean(pair_ms))
+            result = {
+                "metric": "pairwise comparisons/sec",
+                "value": total_pairs / (elapsed / args.steps),
+                "unit": "pairs/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "u32",
+                "data": "synthetic",
+                "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order, "
+                                       f"{world} contiguous ranges, each in its rank's HBM)",
+                           "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs, "path": used,
+                           "partition": f"{world} contiguous row ranges of equal pair count; no collective in the data path "
+                                        "(--exchange gather adds the RCCL send/recv of every slab to rank 0)",
+                           "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
+                           "note": "strong scaling of a step whose per-rank share of the pairs shrinks with N while the pack "
+                                   "and the difference lists of the WHOLE set are rebuilt by every rank each step "
+                                   "(kernels_ms.pack + lists_and_constants): that replicated part bounds the speed-up "
+                                   "(DESIGN.md 6)",
+                           "variant": args.variant},
+                "roofline": roofline(measure, used, k_ms, my_pairs),
+                "kernels_ms": {"rank": 0, "pack": float(np.mean(pack_ms)), "pair": k_ms,
+                               "lists_and_constants": max(0.0, 1e3 * elapsed / args.steps - k_ms - float(np.mean(pack_ms)))},
+                "site_compares_per_s": total_pairs / (elapsed / args.steps) * L,
+                "verify": {"rows_checked": int(v[0].item()), "rows_bad": int(v[1].item()),
+                           "against": "single-engine dense-path run of the same rows, on every rank"},
+            }
+            print(json.dumps(result))
+        assert int(v[1].item()) == 0, "a rank's slab differs from a single-engine dense run"
+        dist.barrier()
+        dist.destroy_process_group()
+        eng.close()
+        return
+
+    # ---------------------------------------------------------------------------------------------
+    # N > 1, --exchange gather: sub-slabs sent to rank 0 while the next one is computed
     # ---------------------------------------------------------------------------------------------
     # On the wire: uint16 tallies when they are smaller than the 8-byte result (raw/jc69: 4 B,
     # n/n_high: 2 B per pair, L < 65,536); rank 0 finalises what it receives (dst_finalize_device,
@@ -515,8 +602,9 @@ def main():
     eng.close()
 
 
-def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream) -> dict:
-    """Sampled rows of the job's result against a fresh single-engine run of just those rows (dense path)."""
+def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream, first_row: int = 0) -> dict:
+    """Sampled rows of the job's result against a fresh single-engine run of just those rows (dense path).
+    `full_out` starts at the first pair of row `first_row`."""
     check = da.Engine(dev_index)
     check.set_path("dense")
     check.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
@@ -525,7 +613,7 @@ def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream) ->
     rows = [r for r in rows if 0 <= r < n - 1]
     for row in rows:
         want = check.run_square(measure, row, row + 1)
-        lo = da.square_row_start(n, row)
+        lo = da.square_row_start(n, row) - da.square_row_start(n, first_row)
         got = full_out[lo:lo + len(want)].cpu().numpy()
         bad += int(not np.array_equal(got, want, equal_nan=True))
     check.close()

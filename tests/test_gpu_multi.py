@@ -26,8 +26,17 @@ def run_ranks(world, port, extra):
 @pytest.mark.parametrize("world,extra", [(3, ["--workload", "C2"]),                                  # raw: uint16 tallies on the wire
                                          (2, ["--workload", "C2", "--measure", "tn93", "--path", "dense"]),  # f64 on the wire, dense kernels
                                          (2, ["--workload", "C2", "--measure", "n_high"])])
-def test_multi_rank_job_matches_a_single_engine(world, extra):
-    d = run_ranks(world, 29500 + world * 7 + len(extra), extra)
+def test_gathered_multi_rank_job_matches_a_single_engine(world, extra):
+    d = run_ranks(world, 29500 + world * 7 + len(extra), ["--exchange", "gather"] + extra)
+    assert d["n_gpus"] == world and d["scaling"] == "strong"
+    assert d["verify"]["rows_bad"] == 0 and d["verify"]["rows_checked"] >= 5
+    assert d["value"] > 0 and d["config"]["pairs"] == 10_000 * 9_999 // 2
+
+
+@pytest.mark.parametrize("world,extra", [(3, ["--workload", "C2"]), (2, ["--workload", "C2", "--measure", "tn93"])])
+def test_sharded_multi_rank_job_matches_a_single_engine(world, extra):
+    """bench.py's default for N>1: every rank's slab stays in its own HBM; every rank checks rows of its slab."""
+    d = run_ranks(world, 29600 + world * 7 + len(extra), extra)
     assert d["n_gpus"] == world and d["scaling"] == "strong"
     assert d["verify"]["rows_bad"] == 0 and d["verify"]["rows_checked"] >= 5
     assert d["value"] > 0 and d["config"]["pairs"] == 10_000 * 9_999 // 2
