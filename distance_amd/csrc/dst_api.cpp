@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 void free_set(DeviceSet &s)
 {
     void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent, s.rec.col,
-                    s.site.cnt, s.site.off, s.site.tab, s.site.inl, s.site.ovf, s.site.ent, s.aconst};
+                    s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -378,16 +378,9 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         return fail(ctx, DST_ERR_CAPACITY, "too many sites x panels for the consensus path's lookup table");
     rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.cnt, &s.site.cnt_cap, (n_buckets + 1) * sizeof(uint32_t));
-    if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.off, &s.site.off_cap, (n_buckets + 1) * sizeof(uint32_t));
-    if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.tab, &s.site.tab_cap, std::max<size_t>(n_buckets, 1) * sizeof(uint2));
-    if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.inl, &s.site.inl_cap, std::max<size_t>(n_buckets, 1) * 2 * sizeof(uint4));
     if (!rc)
-        rc = ensure_bytes(ctx, (void **)&ctx->scan_tmp, &ctx->scan_tmp_bytes,
-                          scan_tmp_words(std::max(s.n + 1, n_buckets + 1)) * sizeof(uint32_t));
+        rc = ensure_bytes(ctx, (void **)&ctx->scan_tmp, &ctx->scan_tmp_bytes, scan_tmp_words(s.n + 1) * sizeof(uint32_t));
     if (rc)
         return rc;
     s.rec.valid = false;
@@ -409,22 +402,13 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         rc = ensure_bytes(ctx, (void **)&s.rec.col, &s.rec.col_cap, (cap + 4) * sizeof(uint16_t));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, cap * sizeof(uint32_t));
-    if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.site.ovf, &s.site.ovf_cap, cap * sizeof(uint2));
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
     HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent, want_sites ? s.rec.col : nullptr,
                               ctx->d_total, stream));
-    if (want_sites) {
-        // the buckets from the lists; then the entries beyond the inline ones (rare: a bucket holds more than
-        // kInlineEvents records of a 2,048-record panel) into bucket order
+    if (want_sites)
         HIP_TRY(ctx, launch_site_buckets(s, n_panels, d_ovf_n, stream));
-        HIP_TRY(ctx, hipMemsetAsync(s.site.off + n_buckets, 0, sizeof(uint32_t), stream));
-        HIP_TRY(ctx, launch_exclusive_scan(s.site.off, n_buckets + 1, ctx->scan_tmp, stream));
-        HIP_TRY(ctx, launch_site_table(s.site.off, s.site.cnt, s.site.tab, n_buckets, stream));
-        HIP_TRY(ctx, launch_ovf_place(s.site.ovf, d_ovf_n, s.site.off, s.site.cnt, s.site.ent, stream));
-    }
     // runs queued on other streams wait for this on the device
     rc = publish_prep(ctx, stream);
     if (rc)
@@ -666,6 +650,12 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         cl.wide = wide;
         cl.d_lut = ctx->d_lut;
         cl.d_hot = d_hot;
+        {   // the sample's view of this launch's event load (the same figures the path choice reads)
+            const uint64_t *st = cols.ref.h_stats;
+            const double S = (double)std::max<uint64_t>(st[3], 1);
+            const double events = (double)(hybrid ? st[7] : st[2]) / (S * S), list = (double)(hybrid ? st[6] : st[1]) / S;
+            cl.heavy_events = events > 0.5 || list > 100.0;
+        }
         ctx->last_path = path;
         if (ntiles) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));

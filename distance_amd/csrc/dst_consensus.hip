@@ -339,71 +339,110 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
 // their sizes are LDS counters and their 32-byte lookup-table entries are assembled in LDS and leave as one
 // contiguous 32 KB piece — no global atomics, no scattered 2-byte writes into the table.  The block streams ALL
 // list entries of the panel's records (16-byte loads; the lists are 1/250 of the planes they were made from) and
-// keeps the ones of its sites; the record of an entry travels beside it (rec_col).  Entries beyond kInlineEvents
-// per bucket go to the overflow list.
+// keeps the ones of its sites; the record of an entry travels beside it (rec_col).
+//   table entry = 16 halfwords: [0] entries in the bucket (<= 2,048), [1..15] entries as record-in-panel | nibble << 11;
+//   a bucket of more than kInlineEvents entries keeps kInlineOverflowing of them inline, its last word is the place
+//   of the others in site_ent (record | nibble << 28).  Such buckets take a second pass over the lists, after the
+//   block has counted them and reserved room for all its overflow entries with ONE global atomic.
 constexpr uint32_t kBucketSites = 1024;
-
 constexpr uint32_t kBucketThreads = 1024;
 
 __global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint32_t *__restrict__ rec_off,
-                                                          const uint32_t *__restrict__ rec_ent,
-                                                          const uint16_t *__restrict__ rec_col, uint32_t n,
-                                                          uint32_t n_sites, uint4 *__restrict__ site_inl,
-                                                          uint32_t *__restrict__ site_cnt, uint32_t *__restrict__ ovf_cnt,
-                                                          uint2 *__restrict__ site_ovf, uint32_t *__restrict__ ovf_n)
+                                                                     const uint32_t *__restrict__ rec_ent,
+                                                                     const uint16_t *__restrict__ rec_col, uint32_t n,
+                                                                     uint32_t n_sites, uint4 *__restrict__ site_inl,
+                                                                     uint32_t *__restrict__ site_ent,
+                                                                     uint32_t *__restrict__ ovf_total)
 {
     constexpr uint32_t NT = kBucketThreads, UNROLL = 4;
+    static_assert(NT == kBucketSites, "one bucket per thread in the offset scan");
     __shared__ uint32_t cnt[kBucketSites];
+    __shared__ uint32_t ooff[kBucketSites];
     __shared__ __attribute__((aligned(16))) uint16_t tabl[kBucketSites][16];
-    const uint32_t panel = blockIdx.y, tid = threadIdx.x;
+    __shared__ uint32_t wave_tot[NT / 64];
+    __shared__ uint32_t blk_base;
+    const uint32_t panel = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t s0 = blockIdx.x * kBucketSites, ns = min(kBucketSites, n_sites - s0);
     const uint32_t r0 = panel * kPanelCols, nrec = min(kPanelCols, n - r0);
-    for (uint32_t k = tid; k < kBucketSites; k += NT)
-        cnt[k] = 0;
+    cnt[tid] = 0;
     for (uint32_t k = tid; k < kBucketSites * 2; k += NT)
         reinterpret_cast<uint4 *>(&tabl[0][0])[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t e0 = rec_off[r0], e1 = rec_off[r0 + nrec];
-    const uint32_t bucket0 = panel * n_sites + s0;
-    // UNROLL 16-byte loads in flight per thread (one at a time the loop is a chain of memory latencies)
-    for (uint32_t ib = (e0 & ~3u) + 4u * tid; ib < e1; ib += 4u * NT * UNROLL) {
-        uint4 v[UNROLL];
-        uint2 vc[UNROLL];
+    // every list entry of the panel whose site is in this block's range: visit(site - s0, record in panel, nibble).
+    // UNROLL 16-byte loads in flight per thread (one at a time the loop is a chain of memory latencies).
+    auto stream_lists = [&](auto &&visit) {
+        for (uint32_t ib = (e0 & ~3u) + 4u * tid; ib < e1; ib += 4u * NT * UNROLL) {
+            uint4 v[UNROLL];
+            uint2 vc[UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < UNROLL; ++u) {
-            const uint32_t i = ib + u * 4u * NT;   // (both arrays have 4 entries of slack at their ends)
-            v[u] = i < e1 ? *reinterpret_cast<const uint4 *>(rec_ent + i) : make_uint4(0, 0, 0, 0);
-            vc[u] = i < e1 ? *reinterpret_cast<const uint2 *>(rec_col + i) : make_uint2(0, 0);
-        }
+            for (uint32_t u = 0; u < UNROLL; ++u) {
+                const uint32_t i = ib + u * 4u * NT;   // (both arrays have 4 entries of slack at their ends)
+                v[u] = i < e1 ? *reinterpret_cast<const uint4 *>(rec_ent + i) : make_uint4(0, 0, 0, 0);
+                vc[u] = i < e1 ? *reinterpret_cast<const uint2 *>(rec_col + i) : make_uint2(0, 0);
+            }
 #pragma unroll
-        for (uint32_t u = 0; u < UNROLL; ++u) {
-            const uint32_t i = ib + u * 4u * NT;
-            const uint32_t ev[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            const uint32_t cv[4] = {vc[u].x & 0xFFFFu, vc[u].x >> 16, vc[u].y & 0xFFFFu, vc[u].y >> 16};
+            for (uint32_t u = 0; u < UNROLL; ++u) {
+                const uint32_t i = ib + u * 4u * NT;
+                const uint32_t ev[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const uint32_t cv[4] = {vc[u].x & 0xFFFFu, vc[u].x >> 16, vc[u].y & 0xFFFFu, vc[u].y >> 16};
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t idx = i + j, sl = (ev[j] & kSiteMask) - s0;
-                if (idx < e0 || idx >= e1 || sl >= ns)
-                    continue;
-                const uint32_t lo = cv[j], nib = ev[j] >> kEntryShift;
-                const uint32_t pos = atomicAdd(&cnt[sl], 1u);
-                if (pos < kInlineEvents)
-                    tabl[sl][1 + pos] = (uint16_t)(lo | nib << 11);
-                else
-                    site_ovf[atomicAdd(ovf_n, 1u)] = make_uint2(bucket0 + sl, (r0 + lo) | nib << kEntryShift);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t idx = i + j, sl = (ev[j] & kSiteMask) - s0;
+                    if (idx >= e0 && idx < e1 && sl < ns)
+                        visit(sl, cv[j], ev[j] >> kEntryShift);
+                }
             }
         }
-    }
+    };
+    // pass 1: sizes, and the entries of every bucket as if it fitted
+    stream_lists([&](uint32_t sl, uint32_t col, uint32_t nib) {
+        const uint32_t pos = atomicAdd(&cnt[sl], 1u);
+        if (pos < kInlineEvents)
+            tabl[sl][1 + pos] = (uint16_t)(col | nib << 11);
+    });
     __syncthreads();
-    for (uint32_t k = tid; k < ns; k += NT) {
-        const uint32_t c = cnt[k];
-        tabl[k][0] = (uint16_t)min(c, 0xFFFFu);
-        site_cnt[bucket0 + k] = c;
-        ovf_cnt[bucket0 + k] = c > kInlineEvents ? c - kInlineEvents : 0u;
+    // room for the overflow entries of this block's buckets: exclusive scan over the buckets + one global atomic
+    const uint32_t c = cnt[tid];
+    const uint32_t over = c > kInlineEvents ? c - kInlineOverflowing : 0u;
+    uint32_t incl = over, up;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        up = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += up;
     }
+    if (lane == 63u)
+        wave_tot[tid >> 6] = incl;
     __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t wv = 0; wv < NT / 64; ++wv) {
+        if (wv < (tid >> 6)) before += wave_tot[wv];
+        total += wave_tot[wv];
+    }
+    if (tid == 0 && total)
+        blk_base = atomicAdd(ovf_total, total);
+    tabl[tid][0] = (uint16_t)c;   // at most kPanelCols: fits the halfword
+    cnt[tid] = 0;
+    __syncthreads();
+    if (total) {   // (uniform over the block)
+        ooff[tid] = blk_base + before + incl - over;
+        if (over)
+            *reinterpret_cast<uint32_t *>(&tabl[tid][14]) = ooff[tid];
+        __syncthreads();
+        // pass 2: the buckets that do not fit, again: kInlineOverflowing entries inline, the others to their place
+        stream_lists([&](uint32_t sl, uint32_t col, uint32_t nib) {
+            if (tabl[sl][0] <= kInlineEvents)
+                return;
+            const uint32_t pos = atomicAdd(&cnt[sl], 1u);
+            if (pos < kInlineOverflowing)
+                tabl[sl][1 + pos] = (uint16_t)(col | nib << 11);
+            else
+                site_ent[ooff[sl] + pos - kInlineOverflowing] = (r0 + col) | nib << kEntryShift;
+        });
+        __syncthreads();
+    }
     for (uint32_t k = tid; k < ns * 2; k += NT)
-        site_inl[(size_t)bucket0 * 2 + k] = reinterpret_cast<const uint4 *>(&tabl[0][0])[k];
+        site_inl[((size_t)panel * n_sites + s0) * 2 + k] = reinterpret_cast<const uint4 *>(&tabl[0][0])[k];
 }
 
 // =============================================================================================
@@ -454,28 +493,6 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
     for (int k = 0; k < 8; ++k)
         if (base + k < n)
             data[base + k] += off;
-}
-
-// {start of the bucket's overflow entries, bucket size}: read only for buckets larger than kInlineEvents
-__global__ __launch_bounds__(256) void site_table_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cur,
-                                                          uint2 *__restrict__ tab, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
-        tab[i] = make_uint2(off[i], cur[i]);
-}
-
-// the overflow list (any order) -> bucket order.  The cursors count down: afterwards cur[b] <= kInlineEvents.
-__global__ __launch_bounds__(256) void ovf_place_kernel(const uint2 *__restrict__ ovf, const uint32_t *__restrict__ ovf_n,
-                                                         const uint32_t *__restrict__ off, uint32_t *__restrict__ cur,
-                                                         uint32_t *__restrict__ site_ent)
-{
-    const uint32_t total = *ovf_n;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const uint2 e = ovf[i];
-        const uint32_t p = atomicSub(&cur[e.x], 1u) - 1u - kInlineEvents;
-        site_ent[off[e.x] + p] = e.y;
-    }
 }
 
 // =============================================================================================
@@ -572,8 +589,22 @@ constexpr bool aligned_output()
 #endif
 }
 
-constexpr int kEventWaves = 4;                     // event waves per workgroup (beside the 4 output waves)
-constexpr uint32_t kEventLanes = 64 * kEventWaves;  // entries of a batch the register pipeline carries
+constexpr int kBlockWaves = 8;   // waves of a workgroup: event waves + output waves
+
+// Event waves per workgroup; the others are output waves.  The events of a low-diversity batch are few (two rows x
+// ~65 entries) and their loads are pipelined, so two waves carry them; the finalisation is what needs the issue
+// slots — more so the more f64 work a result takes (50,000 x 30,000, 4+4 -> 2+6 -> 1+7 waves: raw 2.40 -> see
+// profiles/r02; tn93 16.7 ms at 4+4).
+template <int FAM, bool WIDE, int OUT>
+constexpr int event_waves()
+{
+#ifdef DST_DBG_EVWAVES
+    return DST_DBG_EVWAVES;
+#else
+    return OUT == DST_TN93 || OUT == DST_K80 ? 1 : 2;
+#endif
+}
+constexpr int kEventWavesHeavy = 4;   // launches with many events per pair or long lists (ConsensusLaunch::heavy_events)
 
 // the value must be in its register HERE (an empty asm the compiler cannot move a definition across)
 __device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
@@ -626,11 +657,11 @@ __device__ __forceinline__ void store_result2(int64_t *p, int64_t a, int64_t b)
 // One barrier per batch.  Why two roles: gfx950 counts loads and stores in ONE in-order counter (vmcnt), so a
 // wave that has just issued its result stores cannot consume a younger load before those stores have
 // landed in HBM; the event waves' chains of dependent random loads never queue behind a store this way.
-template <int FAM, bool WIDE, int OUT>
-__global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
+template <int FAM, bool WIDE, int OUT, int EW>
+__global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,
     const uint32_t *__restrict__ row_a, uint32_t row_npad, const uint4 *__restrict__ site_inl,
-    const uint2 *__restrict__ site_tab, const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
+    const uint32_t *__restrict__ site_ent, const uint32_t *__restrict__ col_a, uint32_t col_npad,
     uint32_t n_sites, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
     const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square,
@@ -643,7 +674,10 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
 #else
     constexpr int RB = kAccRows;
 #endif
-    constexpr int PAIRS = kPanelCols / 512;      // column pairs per output thread
+    constexpr int NOW = kBlockWaves - EW;              // EW event waves, NOW output waves
+    constexpr uint32_t kEventLanes = 64 * EW;          // entries of a batch the register pipeline carries
+    constexpr uint32_t OT = 64 * NOW;                  // output threads
+    constexpr int PAIRS = (kPanelCols + 2 * OT - 1) / (2 * OT);   // column pairs per output thread (panel-relative mapping)
     constexpr uint32_t ACC = RB * W * kPanelCols;  // words of one accumulator buffer
     extern __shared__ uint32_t smem[];
     uint32_t *acc = smem;                                  // [2][RB][W][kPanelCols]
@@ -661,8 +695,8 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
     const ConsensusTile tile = tiles[blockIdx.x];
     const uint32_t panel0 = tile.panel * kPanelCols;
     const uint32_t pcols = min(kPanelCols, n_cols - panel0);
-    const bool event_role = threadIdx.x >= 256;
-    const uint32_t tid = threadIdx.x & 255u, lane = tid & 63u;
+    const bool event_role = threadIdx.x >= OT;
+    const uint32_t tid = event_role ? threadIdx.x - OT : threadIdx.x, lane = threadIdx.x & 63u;   // index within the role
     const uint32_t trows = tile.i1 - tile.i0;              // <= kTileRowsMax
     const uint32_t nbatch = (trows + RB - 1) / RB;
     for (uint32_t k = threadIdx.x; k < 2 * ACC; k += blockDim.x)
@@ -684,7 +718,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         for (int j = 0; j < PAIRS; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t k = 2 * tid + 512 * j + h;
+                const uint32_t k = 2 * tid + 2 * OT * j + h;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
@@ -704,7 +738,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
     };
     struct Inl {     // stage 2: the 32-byte lookup-table entry of its site in this panel = the bucket itself
         uint4 lo, hi;        // halfword 0: entries in the bucket (saturating); halfwords 1..15: record-in-panel | nibble << 11
-        uint32_t meta, site;
+        uint32_t meta;
     };
     auto load_entry = [&](uint32_t b, uint32_t first) {   // entry `first + tid` of batch b's run
         Entry en{0u, 0u, false};
@@ -722,10 +756,9 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         return en;
     };
     auto load_inl = [&](const Entry &en) {
-        Inl t{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u, 0u};
+        Inl t{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u};
         if (en.valid) {
-            t.site = en.e & kSiteMask;
-            const uint4 *p = site_inl + 2 * ((size_t)tile.panel * n_sites + t.site);
+            const uint4 *p = site_inl + 2 * ((size_t)tile.panel * n_sites + (en.e & kSiteMask));
             t.lo = p[0];
             t.hi = p[1];
             t.meta = en.rb << 8 | ((en.e >> kSiteBits) & 7u) << 4 | (en.e >> kEntryShift);
@@ -758,19 +791,16 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
         };
         const uint32_t cnt = t.lo.x & 0xFFFFu;
         const uint32_t w8[8] = {t.lo.x, t.lo.y, t.lo.z, t.lo.w, t.hi.x, t.hi.y, t.hi.z, t.hi.w};
+        const bool over = cnt > kInlineEvents;   // then the last word is the place of the other entries, not two of them
+        const uint32_t inl_n = over ? kInlineOverflowing : cnt;
 #pragma unroll
         for (uint32_t k = 1; k <= kInlineEvents; ++k)
-            if (k <= cnt) {
+            if (k <= inl_n) {
                 const uint32_t e16 = (k & 1u) ? w8[k >> 1] >> 16 : w8[k >> 1] & 0xFFFFu;
                 apply(e16 & (kPanelCols - 1u), e16 >> 11, t.meta);
             }
-        if (__ballot(cnt > kInlineEvents)) {
-            uint32_t o0 = 0, ex = 0;
-            if (cnt > kInlineEvents) {
-                const uint2 tab = site_tab[(size_t)tile.panel * n_sites + t.site];
-                o0 = tab.x;   // the entries beyond the inline ones, in the overflow array
-                ex = tab.y - kInlineEvents;
-            }
+        if (__ballot(over)) {
+            const uint32_t o0 = w8[7], ex = over ? cnt - kInlineOverflowing : 0u;
             uint32_t incl = ex, up;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -803,7 +833,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
     // the other way round — the kernel needs the larger of the two register sets, not their sum.
 #define DST_BATCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     if (event_role) {
-        const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u, 0u};
+        const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u};
         Entry en_n2{0u, 0u, false};
         Inl in_cur = inl_none, in_nx = inl_none;
 #ifdef DST_DBG_NO_EVENTS
@@ -833,7 +863,7 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                 Entry en_use = en_n2;
                 pin(in_cur.lo.x), pin(in_cur.lo.y), pin(in_cur.lo.z), pin(in_cur.lo.w);
                 pin(in_cur.hi.x), pin(in_cur.hi.y), pin(in_cur.hi.z), pin(in_cur.hi.w);
-                pin(in_cur.meta), pin(in_cur.site), pin(en_use.e), pin(en_use.rb);
+                pin(in_cur.meta), pin(en_use.e), pin(en_use.rb);
                 __builtin_amdgcn_sched_barrier(0);
                 in_nx = load_inl(en_use);
                 en_n2 = load_entry(step + 3, 0);
@@ -926,31 +956,15 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                         double *out = static_cast<double *>(out_v);
                         double d[2] = {0.0, 0.0};
                         auto fin = [&](int h) {
-                            // h may be a run-time value (tn93's rolled loop): selects, not indexed private arrays
-                            uint32_t oh[NT];
-#pragma unroll
-                            for (int x = 0; x < NT; ++x)
-                                oh[x] = h == 0 ? o[0][x] : o[1][x];
-                            if (h == 0 ? live[0] : live[1]) {
+                            if (live[h]) {
                                 uint4 tc = make_uint4(0, 0, 0, 0);
                                 if constexpr (OUT == DST_TN93)
                                     tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
-                                const double r = finalize_pair<OUT>(oh, qc, tc);
-                                if (h == 0)
-                                    d[0] = r;
-                                else
-                                    d[1] = r;
+                                d[h] = finalize_pair<OUT>(o[h], qc, tc);
                             }
                         };
-                        if constexpr (OUT == DST_TN93) {
-                            // one copy of the formula, not two: tn93's registers decide how many workgroups fit a CU
-#pragma unroll 1
-                            for (int h = 0; h < 2; ++h)
-                                fin(h);
-                        } else {
-                            fin(0);
-                            fin(1);
-                        }
+                        fin(0);   // (two copies of the formula: the two results' dependency chains interleave)
+                        fin(1);
 #ifdef DST_DBG_NO_STORE
                         if (d[0] != -12345.5)
                             return;
@@ -966,26 +980,28 @@ __global__ __launch_bounds__(256 + 64 * kEventWaves, OUT == DST_TN93 ? 4 : 2) vo
                 };
                 if constexpr (ALIGNED) {
                     // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
-                    // or 17 lines-of-1-KB groups from that line's start go to the four output waves as contiguous
-                    // runs of 4 (one wave, rotating with the row, takes 5): a wave's stores are whole, consecutive
-                    // lines; only the panel's two edge lines are shared with the neighbouring tiles.
+                    // or 17 lines-of-1-KB groups from that line's start go to the output waves as contiguous runs:
+                    // a wave's stores are whole, consecutive lines; only the panel's two edge lines are shared with
+                    // the neighbouring tiles.
                     constexpr uint32_t ELEM = OUT == OUT_TALLY ? 4u * NT : OUT == OUT_TALLY16 ? 2u * NT : 8u;
                     const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(out_v) / ELEM + row_at + panel0) & 15u);
-                    const uint32_t wv = tid >> 6, extra = q & 3u;
-                    const uint32_t g0 = 4u * wv + (wv > extra ? 1u : 0u);
+                    // 17 groups over NOW waves: BASE each, the first REM waves (in an order rotating with the row) one more
+                    constexpr uint32_t GROUPS = kPanelCols / 128 + 1, BASE = GROUPS / NOW, REM = GROUPS % NOW;
+                    const uint32_t wv = tid >> 6, idx = (wv + NOW - q % NOW) % NOW;
+                    const uint32_t g0 = idx * BASE + min(idx, REM);
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; ++g)
+                    for (uint32_t g = 0; g < BASE; ++g)
                         do_pair((int32_t)(128u * (g0 + g) + 2u * lane) - (int32_t)sh, 0);
-                    if (wv == extra)
-                        do_pair((int32_t)(128u * (g0 + 4u) + 2u * lane) - (int32_t)sh, 0);
+                    if (idx < REM)
+                        do_pair((int32_t)(128u * (g0 + BASE) + 2u * lane) - (int32_t)sh, 0);
                 } else if constexpr (HOIST) {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair((int32_t)(2 * tid + 512 * j), j);
+                        do_pair((int32_t)(2 * tid + 2 * OT * j), j);
                 } else {
 #pragma unroll 1
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair((int32_t)(2 * tid + 512 * j), j);
+                        do_pair((int32_t)(2 * tid + 2 * OT * j), j);
                 }
             }
         }
@@ -1070,12 +1086,12 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_n, hipStream_t stream)
+hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream)
 {
     const uint32_t n_sites = (uint32_t)(set.nchunks * kChunkSites);
-    hipLaunchKernelGGL(site_bucket_kernel, dim3((n_sites + kBucketSites - 1) / kBucketSites, n_panels), dim3(kBucketThreads), 0, stream,
-                       set.rec.off, set.rec.ent, set.rec.col, (uint32_t)set.n, n_sites, set.site.inl, set.site.cnt, set.site.off,
-                       set.site.ovf, ovf_n);
+    hipLaunchKernelGGL(site_bucket_kernel, dim3((n_sites + kBucketSites - 1) / kBucketSites, n_panels), dim3(kBucketThreads), 0,
+                       stream, set.rec.off, set.rec.ent, set.rec.col, (uint32_t)set.n, n_sites, set.site.inl, set.site.ent,
+                       ovf_total);
     return hipGetLastError();
 }
 
@@ -1105,21 +1121,6 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cur, uint2 *tab, size_t n, hipStream_t stream)
-{
-    if (n == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(site_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, off, cur, tab, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_ovf_place(const uint2 *ovf, const uint32_t *ovf_n, const uint32_t *off, uint32_t *cur, uint32_t *site_ent,
-                            hipStream_t stream)
-{
-    hipLaunchKernelGGL(ovf_place_kernel, dim3(512), dim3(256), 0, stream, ovf, ovf_n, off, cur, site_ent);
-    return hipGetLastError();
-}
-
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream)
 {
     hipLaunchKernelGGL(aconst_kernel, dim3((unsigned)((set.n + 3) / 4)), dim3(256), 0, stream, set.rec.off,
@@ -1130,8 +1131,8 @@ hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const Cons
 
 namespace {
 
-template <int FAM, bool WIDE, int OUT>
-hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
+template <int FAM, bool WIDE, int OUT, int EW>
+hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
     constexpr int W = Pack<FAM, WIDE>::W;
 #ifdef DST_DBG_RB
@@ -1141,19 +1142,27 @@ hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t
 #endif
     const size_t smem = ((size_t)2 * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
                          (aligned_output<FAM, WIDE, OUT>() ? kPanelCols : 0)) * sizeof(uint32_t);
-    auto kern = consensus_pair_kernel<FAM, WIDE, OUT>;
+    auto kern = consensus_pair_kernel<FAM, WIDE, OUT, EW>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(256 + 64 * kEventWaves), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
-                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.inl, cl.cols->site.tab, cl.cols->site.ent,
+    hipLaunchKernelGGL(kern, dim3(cl.ntiles), dim3(64 * kBlockWaves), smem, stream, cl.rows->rec.off, cl.rows->rec.ent,
+                       cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.inl, cl.cols->site.ent,
                        cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
                        (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0, cl.d_hot);
     return hipGetLastError();
+}
+
+template <int FAM, bool WIDE, int OUT>
+hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
+{
+    if (cl.heavy_events)
+        return launch_cpair_ew<FAM, WIDE, OUT, kEventWavesHeavy>(cl, fw, stream);
+    return launch_cpair_ew<FAM, WIDE, OUT, event_waves<FAM, WIDE, OUT>()>(cl, fw, stream);
 }
 
 template <int FAM, bool WIDE>

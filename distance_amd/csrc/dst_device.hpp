@@ -55,6 +55,9 @@ __device__ __forceinline__ double dst_log(double x)
 // ---- finalisation math: tallies -> f64 in the reference's operation order ---------------------
 __device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
 {
+#ifdef DST_DBG_CHEAPFIN
+    return (double)n + (double)d;
+#endif
     return (double)n / (double)d;
 }
 

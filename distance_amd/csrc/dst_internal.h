@@ -53,6 +53,7 @@ constexpr uint32_t kEntryMask = (1u << kEntryShift) - 1;   // bucket entries: co
 constexpr uint32_t kSiteBits = 25;         // record-list entries: site | reference class << 25 | nibble << 28
 constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
 constexpr uint32_t kInlineEvents = 15;     // bucket entries held inside the 32-byte lookup-table entry
+constexpr uint32_t kInlineOverflowing = 13;  // ... of a larger bucket: its last word is where the rest are
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
 constexpr uint32_t kHotPermille = 33;      // hybrid path: a site is "hot" when more than 3.3 % of the sampled records deviate
@@ -82,18 +83,13 @@ struct RecordIndex {              // per record: the sites where it differs from
 };
 
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
-    uint32_t *cnt = nullptr;      // [n_sites * n_panels + 1] fill cursors = entries per bucket
-    uint32_t *off = nullptr;      // [n_sites * n_panels + 1] start of the bucket's overflow entries in `ent`
-    uint2 *tab = nullptr;         // [n_sites * n_panels] {overflow start, entries}
-    uint2 *ovf = nullptr;         // {bucket, entry} of the entries beyond the inline ones, in the order they were found
-    size_t ovf_cap = 0;
-    // [n_sites * n_panels] 32 bytes per bucket = 16 halfwords: entries (saturating), then the first kInlineEvents
+    // [n_sites * n_panels] 32 bytes per bucket = 16 halfwords: [0] entries in the bucket, then up to kInlineEvents
     // entries as record-in-panel | nibble << 11.  The pair kernel reads THIS: one request per (row entry, panel)
-    // brings the whole bucket of a typical site; `tab` + `ent` serve the buckets that are larger.
+    // brings the whole bucket of a typical site.  A larger bucket keeps kInlineOverflowing entries inline and its
+    // last word is the place of the others in `ent`.
     uint4 *inl = nullptr;
-    size_t inl_cap = 0;
     uint32_t *ent = nullptr;      // overflow entries by bucket: record | nibble << 28 (any order inside a bucket)
-    size_t cnt_cap = 0, off_cap = 0, tab_cap = 0, ent_cap = 0;
+    size_t inl_cap = 0, ent_cap = 0;
     uint32_t n_panels = 0;
     bool valid = false;
 };
@@ -183,6 +179,7 @@ struct ConsensusLaunch {
     bool wide;                   // one 32-bit word per tally (alignments of 65,536 sites or more)
     const ConsensusLut *d_lut;
     const void *d_hot = nullptr; // hybrid path: the dense kernels' tallies of the hot columns (TALLY16 / TALLY layout)
+    bool heavy_events = false;   // many events per pair or long lists: more of the workgroup's waves take the event role
 };
 
 // ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
@@ -195,17 +192,13 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
                         uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total,
                         hipStream_t stream);
-// a column set's site buckets from its lists (set.rec -> set.site: 32-byte table entries, sizes, overflow counts + list)
-hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_n, hipStream_t stream);
+// a column set's site buckets from its lists (set.rec -> set.site); *ovf_total (zeroed by the caller) counts the
+// overflow entries placed in set.site.ent
+hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
-// after the fill pass: bucket sizes -> table entries + overflow counts (scanned next), {overflow start, size}
-// per bucket, and the overflow list into bucket order
-hipError_t launch_site_table(const uint32_t *off, const uint32_t *cur, uint2 *tab, size_t n, hipStream_t stream);
-hipError_t launch_ovf_place(const uint2 *ovf, const uint32_t *ovf_n, const uint32_t *off, uint32_t *cur, uint32_t *site_ent,
-                            hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
                                   hipStream_t stream);
