@@ -51,7 +51,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent, s.rec.col,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals,
                     s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -89,24 +89,84 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.loaded = false;
     s.have_counts = false;
     s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
-    s.ref.valid = s.rec.valid = s.site.valid = false;
+    s.ref.valid = s.rec.valid = s.site.valid = s.rec.pre_valid = false;
     s.aconst_family = -1;
     return DST_OK;
 }
 
+// buffers of a set's reference sequence (dst_consensus.hip)
+int alloc_ref(dst_ctx *ctx, DeviceSet &s)
+{
+    if (s.ref.nchunks == s.nchunks && s.ref.planes)
+        return DST_OK;
+    for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats})
+        if (b)
+            HIP_TRY(ctx, hipFree(b));
+    s.ref.planes = nullptr;
+    s.ref.hot_planes = nullptr;
+    s.ref.hot_sites = nullptr;
+    s.ref.stats = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
+    HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_planes, s.nchunks * sizeof(uint4)));
+    HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_sites, s.nchunks * kChunkSites * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 8 * sizeof(uint64_t)));
+    s.ref.nchunks = s.nchunks;
+    return DST_OK;
+}
+
+// Lists are only worth counting while the sampled records deviate from the reference at less than this share of the
+// sites (unstructured data crosses over to the dense path near 3-4 %; profiles/r02/consensus_calibration.txt)
+constexpr double kListsMaxDeviation = 0.08;
+
 // queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the first
 // offending byte's index (or stays ~0).  Nothing here waits for the device.
+// want_lists: the consensus path is likely to run on this set — its reference sequence is sampled from the bytes
+// first and the pack counts every record's differences from it on the way (pre_cold / pre_hot), which is the
+// consensus path's first pass over the planes; the caller's one synchronisation then also brings the statistics.
 int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
-               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream)
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists)
 {
     int rc = shape_set(ctx, s, n, len);
     if (rc)
         return rc;
+    PackLists pl{};
+    if (want_lists) {
+        rc = alloc_ref(ctx, s);
+        if (!rc && s.rec.pre_cap < n + 1) {
+            for (void *b : {(void *)s.rec.pre_cold, (void *)s.rec.pre_hot, (void *)s.rec.pre_totals})
+                if (b)
+                    HIP_TRY(ctx, hipFree(b));
+            s.rec.pre_cold = s.rec.pre_hot = nullptr;
+            s.rec.pre_totals = nullptr;
+            s.rec.pre_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, (n + 1) * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_hot, (n + 1) * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_totals, 2 * sizeof(unsigned long long)));
+            s.rec.pre_cap = n + 1;
+        }
+        if (rc)
+            return rc;
+        HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 8 * sizeof(uint64_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (n + 1) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_hot, 0, (n + 1) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream));
+        HIP_TRY(ctx, launch_hot_list(s, stream));
+        pl.ref_planes = s.ref.planes;
+        pl.hot_planes = s.ref.hot_planes;
+        pl.stats = reinterpret_cast<const unsigned long long *>(s.ref.stats);
+        pl.max_dev_sum = (unsigned long long)(kListsMaxDeviation * (double)len * (double)std::min<size_t>(n, kRefSamples));
+        pl.cnt_cold = s.rec.pre_cold;
+        pl.cnt_hot = s.rec.pre_hot;
+    }
     HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, stream));
+    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, want_lists ? &pl : nullptr, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->timed_pack = true;
+    if (want_lists) {
+        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_totals, 0, 2 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, launch_sum2_u32(s.rec.pre_cold, s.rec.pre_hot, n, s.rec.pre_totals, stream));
+    }
     if (d_counts) {
         HIP_TRY(ctx, hipMemsetAsync(s.counts, 0, s.npad * 4 * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemcpyAsync(s.counts, d_counts, n * 4 * sizeof(uint32_t),
@@ -125,20 +185,38 @@ int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len)
     return fail(ctx, DST_ERR_INVALID_CODE, msg);
 }
 
+bool consensus_shape_ok(const DeviceSet &rows, const DeviceSet &cols);
+
 int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, size_t len,
                      size_t row_stride, const uint32_t *d_counts, hipStream_t stream)
 {
     DeviceSet &s = ctx->set[slot];
-    int rc = pack_queue(ctx, s, d_codes, n, len, row_stride, d_counts, ctx->d_first_bad, stream);
+    // the consensus path's preparation rides on the pack when a run of this set is likely to take it: not forced
+    // dense, a shape the lists can index, and more work than the dense kernels finish before lists are built
+    const bool want_lists = ctx->path != DST_PATH_DENSE && n >= 2 && len > 0 && n < kEntryMask && len < kSiteMask &&
+                            0.5 * (double)n * (double)n * (double)len >= 2.0e10;
+    int rc = pack_queue(ctx, s, d_codes, n, len, row_stride, d_counts, ctx->d_first_bad, stream, want_lists);
     if (rc)
         return rc;
-    unsigned long long first_bad = 0;
+    unsigned long long first_bad = 0, totals[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof first_bad, hipMemcpyDeviceToHost,
                                 stream));
+    if (want_lists) {
+        HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipMemcpyAsync(totals, s.rec.pre_totals, sizeof totals, hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (first_bad != ~0ull)
         return invalid_code_error(ctx, first_bad, len);
     s.loaded = true;
+    if (want_lists) {
+        s.ref.valid = true;
+        const double max_dev = kListsMaxDeviation * (double)len * (double)std::min<size_t>(n, kRefSamples);
+        s.rec.pre_valid = (double)s.ref.h_stats[1] <= (double)(unsigned long long)max_dev;   // the kernel's own test
+        s.rec.pre_epoch = s.epoch;
+        s.rec.pre_total_cold = totals[0];
+        s.rec.pre_total_hot = totals[1];
+    }
     return DST_OK;
 }
 
@@ -309,20 +387,9 @@ int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
     if (s.ref.valid)
         return DST_OK;
-    if (s.ref.nchunks != s.nchunks || !s.ref.planes) {
-        for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats})
-            if (b)
-                HIP_TRY(ctx, hipFree(b));
-        s.ref.planes = nullptr;
-        s.ref.hot_planes = nullptr;
-        s.ref.hot_sites = nullptr;
-        s.ref.stats = nullptr;
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_planes, s.nchunks * sizeof(uint4)));
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_sites, s.nchunks * kChunkSites * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 8 * sizeof(uint64_t)));
-        s.ref.nchunks = s.nchunks;
-    }
+    int rc_alloc = alloc_ref(ctx, s);
+    if (rc_alloc)
+        return rc_alloc;
     HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 8 * sizeof(uint64_t), stream));
     HIP_TRY(ctx, launch_ref_sample(s, stream));
     HIP_TRY(ctx, launch_hot_list(s, stream));
@@ -386,13 +453,23 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     s.rec.valid = false;
     s.site.valid = false;
     uint32_t *d_ovf_n = reinterpret_cast<uint32_t *>(ctx->d_total + 1);
-    HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, nullptr, ctx->d_total, stream));
     unsigned long long total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (&s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch) {
+        // the pack counted the list lengths against this very reference: no pass over the planes, no round trip
+        HIP_TRY(ctx, hipMemcpyAsync(s.rec.off, s.rec.pre_cold, (s.n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        total = s.rec.pre_total_cold;
+        if (!without_hot && s.rec.pre_total_hot) {
+            HIP_TRY(ctx, launch_add_u32(s.rec.off, s.rec.pre_hot, s.n, stream));
+            total += s.rec.pre_total_hot;
+        }
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, nullptr, ctx->d_total, stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+    }
     if (total > kMaxListEntries / 4)
         return fail(ctx, DST_ERR_CAPACITY, "too many differences from the reference sequence for the consensus path");
     s.rec.total = total;

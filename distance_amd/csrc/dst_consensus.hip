@@ -49,37 +49,68 @@ __device__ __forceinline__ uint32_t popc4(uint4 v)
 // class counts meet in LDS.  Every thread of a group reads the same 16 bytes of a sampled record (broadcast).
 // Classes: known A, G, C, T and the N class (N, -, ?); ties go to the first in that order.  Any choice
 // gives exact results — the reference only decides how much work the pair kernel has.
-__global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restrict__ planes32, uint32_t n,
+// record of sample k: floor(k n / samples) without a 64-bit division (samples is kRefSamples = 512, or n when n is smaller)
+__device__ __forceinline__ uint32_t sample_record(uint32_t k, uint32_t n, uint32_t samples)
+{
+    static_assert(kRefSamples == 512, "shifts below");
+    return samples == n ? k : k * (n >> 9) + ((k * (n & 511u)) >> 9);
+}
+
+// BYTES: the sample is read from the row-major code matrix itself (high nibble = the A,G,C,T plane bits), so the
+// reference exists BEFORE the pack and the pack can count every record's differences on its way (dst_kernels.hip).
+template <bool BYTES>
+__global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const uint32_t *__restrict__ planes32,
+                                                         const uint8_t *__restrict__ codes, size_t row_stride, uint32_t n,
                                                          uint32_t len, uint32_t nchunks, uint32_t npad,
                                                          uint32_t samples, uint4 *__restrict__ ref_planes,
                                                          uint4 *__restrict__ hot_planes,
                                                          unsigned long long *__restrict__ stats)
 {
-    __shared__ uint32_t part[4][5][128];
+    // GROUPS groups of 128 threads, thread = (site, every GROUPS-th sample), UNR sampled records per round: their
+    // loads are issued together (one record at a time this kernel was a chain of 128 memory latencies on one block
+    // per CU: 0.12 ms for 8 MB)
+    constexpr uint32_t GROUPS = BYTES ? 8 : 4, UNR = BYTES ? 16 : 8;
+    __shared__ uint32_t part[GROUPS][5][128];
     const uint32_t c = blockIdx.x, b = threadIdx.x & 127u, grp = threadIdx.x >> 7;
     const uint32_t w = b >> 5, bit = b & 31;
     const size_t ps = (size_t)nchunks * npad * 4;  // plane stride in 32-bit words
     uint32_t cnt[5] = {0, 0, 0, 0, 0};
-    // 8 sampled records per round: their 32 loads are issued together (one record at a time this kernel was a chain
-    // of 128 memory latencies on one block per CU: 0.12 ms for 8 MB)
-    for (uint32_t k0 = grp; k0 < samples; k0 += 32) {
-        uint32_t pw[8][4];
+    for (uint32_t k0 = grp; k0 < samples; k0 += GROUPS * UNR) {
+        uint32_t nibs[UNR];
+        if constexpr (BYTES) {
+            uint32_t by[UNR];
+            const uint32_t site = c * kChunkSites + b;
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t k = k0 + 4 * u;
-            const uint32_t r = (uint32_t)(((uint64_t)min(k, samples - 1) * n) / samples);
-            const size_t at = ((size_t)c * npad + r) * 4 + w;
-            pw[u][0] = planes32[PL_A * ps + at];
-            pw[u][1] = planes32[PL_G * ps + at];
-            pw[u][2] = planes32[PL_C * ps + at];
-            pw[u][3] = planes32[PL_T * ps + at];
+            for (uint32_t u = 0; u < UNR; ++u) {
+                const uint32_t k = k0 + GROUPS * u;
+                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
+                by[u] = site < len ? codes[(size_t)r * row_stride + site] : 0xF0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u)
+                nibs[u] = by[u] >> 4;
+        } else {
+            uint32_t pw[UNR][4];
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u) {
+                const uint32_t k = k0 + GROUPS * u;
+                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
+                const size_t at = ((size_t)c * npad + r) * 4 + w;
+                pw[u][0] = planes32[PL_A * ps + at];
+                pw[u][1] = planes32[PL_G * ps + at];
+                pw[u][2] = planes32[PL_C * ps + at];
+                pw[u][3] = planes32[PL_T * ps + at];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u)
+                nibs[u] = ((pw[u][0] >> bit) & 1u) << 3 | ((pw[u][1] >> bit) & 1u) << 2 |
+                          ((pw[u][2] >> bit) & 1u) << 1 | ((pw[u][3] >> bit) & 1u);
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            if (k0 + 4 * u >= samples)
+        for (uint32_t u = 0; u < UNR; ++u) {
+            if (k0 + GROUPS * u >= samples)
                 break;
-            const uint32_t nib = ((pw[u][0] >> bit) & 1u) << 3 | ((pw[u][1] >> bit) & 1u) << 2 |
-                                 ((pw[u][2] >> bit) & 1u) << 1 | ((pw[u][3] >> bit) & 1u);
+            const uint32_t nib = nibs[u];
             cnt[0] += nib == 8;
             cnt[1] += nib == 4;
             cnt[2] += nib == 2;
@@ -94,8 +125,12 @@ __global__ __launch_bounds__(512) void ref_sample_kernel(const uint32_t *__restr
     if (grp != 0)
         return;
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
-        cnt[k] = part[0][k][b] + part[1][k][b] + part[2][k][b] + part[3][k][b];
+    for (int k = 0; k < 5; ++k) {
+        cnt[k] = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < GROUPS; ++g)
+            cnt[k] += part[g][k][b];
+    }
     uint32_t best = cnt[0], cls = 0;
 #pragma unroll
     for (uint32_t k = 1; k < 5; ++k)
@@ -493,6 +528,35 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
     for (int k = 0; k < 8; ++k)
         if (base + k < n)
             data[base + k] += off;
+}
+
+// totals[k] += sum of a[k][0..n) for the two count arrays of the pack (totals zeroed by the caller)
+__global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restrict__ a0, const uint32_t *__restrict__ a1, size_t n,
+                                                       unsigned long long *__restrict__ totals)
+{
+    unsigned long long s0 = 0, s1 = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        s0 += a0[i];
+        s1 += a1[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (s0)
+            atomicAdd(&totals[0], s0);
+        if (s1)
+            atomicAdd(&totals[1], s1);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        dst[i] += src[i];
 }
 
 // =============================================================================================
@@ -1049,11 +1113,20 @@ __global__ __launch_bounds__(128) void site_hist_kernel(const uint32_t *__restri
 // =============================================================================================
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
 {
-    const uint32_t samples = (uint32_t)std::min<size_t>(set.n, 512);
-    hipLaunchKernelGGL(ref_sample_kernel, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
-                       reinterpret_cast<const uint32_t *>(set.planes), (uint32_t)set.n, (uint32_t)set.len,
+    const uint32_t samples = (uint32_t)std::min<size_t>(set.n, kRefSamples);
+    hipLaunchKernelGGL(ref_sample_kernel<false>, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
+                       reinterpret_cast<const uint32_t *>(set.planes), nullptr, 0, (uint32_t)set.n, (uint32_t)set.len,
                        (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes, set.ref.hot_planes,
                        reinterpret_cast<unsigned long long *>(set.ref.stats));
+    return hipGetLastError();
+}
+
+hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream)
+{
+    const uint32_t samples = (uint32_t)std::min<size_t>(set.n, kRefSamples);
+    hipLaunchKernelGGL(ref_sample_kernel<true>, dim3((unsigned)set.nchunks), dim3(1024), 0, stream, nullptr, d_codes, row_stride,
+                       (uint32_t)set.n, (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
+                       set.ref.hot_planes, reinterpret_cast<unsigned long long *>(set.ref.stats));
     return hipGetLastError();
 }
 
@@ -1118,6 +1191,19 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, stream, data, n, tmp);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sum2_u32_kernel, dim3((unsigned)std::min<size_t>(256, (n + 255) / 256 + 1)), dim3(256), 0, stream, a0, a1, n, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

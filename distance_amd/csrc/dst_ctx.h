@@ -81,7 +81,7 @@ void free_set(DeviceSet &s);
 // queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the index of the first
 // byte that is not a Paradis code (or stays ~0).  Nothing here waits for the device.
 int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
-               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream);
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists);
 int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len);
 // rows [rb, re) of `rows` against every (square: later) record of `cols` — any two packed sets of this context
 int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet &cols, uint64_t rb, uint64_t re,

@@ -54,6 +54,7 @@ constexpr uint32_t kSiteBits = 25;         // record-list entries: site | refere
 constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
 constexpr uint32_t kInlineEvents = 15;     // bucket entries held inside the 32-byte lookup-table entry
 constexpr uint32_t kInlineOverflowing = 13;  // ... of a larger bucket: its last word is where the rest are
+constexpr uint32_t kRefSamples = 512;      // records sampled for the reference sequence
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
 constexpr uint32_t kHotPermille = 33;      // hybrid path: a site is "hot" when more than 3.3 % of the sampled records deviate
@@ -74,6 +75,13 @@ struct RecordIndex {              // per record: the sites where it differs from
     uint32_t *off = nullptr;      // [n + 1]
     uint32_t *ent = nullptr;      // site | class of the reference there << 25 | the record's nibble << 28
     uint16_t *col = nullptr;      // column sets: the entry's record within its panel (read by site_bucket_kernel)
+    // list lengths counted by the pack itself against the set's own reference (cold sites / hot sites apart), with
+    // their sums {cold, hot} — valid while pre_epoch == the set's epoch
+    uint32_t *pre_cold = nullptr, *pre_hot = nullptr;
+    unsigned long long *pre_totals = nullptr;
+    size_t pre_cap = 0;
+    uint64_t pre_epoch = 0, pre_total_cold = 0, pre_total_hot = 0;
+    bool pre_valid = false;
     size_t off_cap = 0, ent_cap = 0, col_cap = 0;
     uint64_t total = 0;
     const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
@@ -184,6 +192,8 @@ struct ConsensusLaunch {
 
 // ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
+// the same from the row-major code matrix (before the pack)
+hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream);
 // count pass (fill == false): rec_cnt[n], site_cnt[len * n_panels] (when want_sites), *total
 // fill pass: entries behind the scanned offsets.  ref_planes: [4][nchunks] uint4.
 hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
@@ -199,6 +209,8 @@ hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t
 size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
+hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream);   // dst[i] += src[i]
+hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
                                   hipStream_t stream);
@@ -206,8 +218,15 @@ hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const 
 hipError_t launch_site_hist(const DeviceSet &set, uint32_t *hist, hipStream_t stream);
 
 // ---- kernel launchers (dst_kernels.hip) -----------------------------------------------------
+// lists != NULL: the pack also counts every record's differences from the reference (cold and hot sites apart)
+struct PackLists {
+    const uint4 *ref_planes, *hot_planes;      // [4][nchunks], [nchunks]
+    const unsigned long long *stats;           // the sample's statistics (device): [1] = sum of deviants
+    unsigned long long max_dev_sum;            // count only while stats[1] <= this (high-diversity sets go dense anyway)
+    uint32_t *cnt_cold, *cnt_hot;              // [n], zeroed
+};
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
-                       unsigned long long *d_first_bad, hipStream_t stream);
+                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
 hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,

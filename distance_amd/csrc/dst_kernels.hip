@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                                                    uint32_t nchunks, uint32_t npad,
                                                    uint4 *__restrict__ planes,
                                                    unsigned long long *__restrict__ first_bad,
-                                                   int aligned16)
+                                                   int aligned16, PackLists lists)
 {
     const uint32_t s = blockIdx.y * blockDim.x + threadIdx.x;
     const uint32_t c = blockIdx.x;
@@ -135,6 +135,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
         }
         if (bad_at != 0xFFFFFFFFu)
             atomicMin(first_bad, (unsigned long long)s * len + site0 + bad_at);
+    }
+    // The consensus path's first pass, for free: how many sites of this (record, chunk) differ from the reference
+    // sequence (sampled from the bytes before this kernel).  Cold and hot sites apart: the hybrid path leaves the hot
+    // ones out of the lists.  Skipped when the sample says the set is too diverse for lists.
+    if (lists.ref_planes && lists.stats[1] <= lists.max_dev_sum) {
+        uint32_t cold = 0, hot = 0;
+        if (s < n) {
+            const uint4 h4 = lists.hot_planes[c];
+            const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w};
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p <= PL_T; ++p) {
+                const uint4 r4 = lists.ref_planes[(size_t)p * nchunks + c];
+                const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    d[w] |= out[p][w] ^ rw[w];
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                cold += __builtin_popcount(d[w] & ~hw[w]);
+                hot += __builtin_popcount(d[w] & hw[w]);
+            }
+            if (cold)
+                atomicAdd(&lists.cnt_cold[s], cold);
+            if (hot)
+                atomicAdd(&lists.cnt_hot[s], hot);
+        }
     }
 #pragma unroll
     for (int p = 0; p < PL_COUNT; ++p)
@@ -546,13 +574,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tal
 // launchers
 // =============================================================================================
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
-                       unsigned long long *d_first_bad, hipStream_t stream)
+                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream)
 {
+    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     const int aligned16 = (reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0);
     dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
-                       d_first_bad, aligned16);
+                       d_first_bad, aligned16, lists ? *lists : none);
     return hipGetLastError();
 }
 

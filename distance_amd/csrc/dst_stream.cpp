@@ -170,7 +170,7 @@ int dst_stream_submit(dst_stream *s, size_t n_records, int use_base_counts)
     HIP_TRY(ctx, hipStreamWaitEvent(s->s_compute, sl.h2d, 0));
     int rc = pack_queue(ctx, sl.set, sl.d_in, n_records, s->len, s->pitch,
                         use_base_counts ? reinterpret_cast<const uint32_t *>(sl.d_in + counts_offset(s)) : nullptr,
-                        sl.d_bad, s->s_compute);
+                        sl.d_bad, s->s_compute, false);
     if (rc)
         return rc;
     sl.set.loaded = true;  // validity is reported by dst_stream_collect
