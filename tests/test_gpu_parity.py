@@ -285,6 +285,49 @@ def test_device_finalisation_over_a_sweep_of_tallies(eng):
         assert np.array_equal(np.signbit(got[zero]), np.signbit(want[zero])), m     # -0.0 where the reference has it
 
 
+def test_raw_quotient_is_the_ieee_division_bit_for_bit(eng):
+    """fin_raw computes n / d from an f32 reciprocal, one Newton step and Markstein's correction (dst_device.hpp); the
+    reference executes an IEEE division (src/measures.rs:68).  Every n <= d below 2,900, the neighbourhood of the
+    16-bit tallies' top, a few million random 24-bit operands and the operands that fall back to the division
+    (d = 0, tallies of 2^24 and more) must give the same bits as numpy's division."""
+    import torch
+    if eng.path_name != "dense":
+        pytest.skip("finalisation is shared by the paths: once is enough")
+    dev = torch.device("cuda", 0)
+    n_rec = 2900                                             # 2,900 records: 4,203,550 pairs to carry the operands
+    eng.upload(0, random_alignment(n_rec, 16, 5))
+    pairs = n_rec * (n_rec - 1) // 2
+    rng = np.random.default_rng(11)
+
+    def check(nn, dd):
+        t = np.zeros((pairs, 2), np.uint32)
+        k = min(pairs, len(nn))
+        t[:k, 0], t[:k, 1] = nn[:k], dd[:k]
+        t[k:, 1] = 1
+        d_t = torch.from_numpy(t).to(dev)
+        d_o = torch.empty(pairs, dtype=torch.float64, device=dev)
+        eng.finalize_device("raw", 0, n_rec, d_t.data_ptr(), d_o.data_ptr(), pairs * 8, tally_kind=da.OUT_TALLY)
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy()[:k]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = t[:k, 0].astype(np.float64) / t[:k, 1].astype(np.float64)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) or \
+            np.array_equal(got[~np.isnan(want)].view(np.uint64), want[~np.isnan(want)].view(np.uint64)) and \
+            np.isnan(got[np.isnan(want)]).all()
+
+    dd, nn = np.meshgrid(np.arange(1, 2899, dtype=np.uint32), np.arange(0, 2899, dtype=np.uint32))
+    keep = nn <= dd
+    check(nn[keep], dd[keep])                                                       # exhaustive small operands
+    d2 = rng.integers(60000, 65536, pairs).astype(np.uint32)
+    check((rng.random(pairs) * d2).astype(np.uint32), d2)                           # top of the 16-bit tallies
+    d3 = rng.integers(1, 1 << 24, pairs).astype(np.uint32)
+    check((rng.random(pairs) * d3).astype(np.uint32), d3)                           # any 24-bit operands, n <= d
+    check(rng.integers(0, 1 << 24, pairs).astype(np.uint32), rng.integers(1, 1 << 24, pairs).astype(np.uint32))  # n > d too
+    d4 = rng.integers(0, 1 << 26, pairs).astype(np.uint32)
+    d4[:1000] = 0
+    check(rng.integers(0, 1 << 26, pairs).astype(np.uint32), d4)                    # the division's own cases
+
+
 def test_in_order_slab_sink(eng):
     """dst_run_slabs: slabs arrive strictly in canonical order and concatenate to the full result."""
     a = random_alignment(150, 400, 33)
