@@ -51,7 +51,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals,
                     s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -99,17 +99,19 @@ int alloc_ref(dst_ctx *ctx, DeviceSet &s)
 {
     if (s.ref.nchunks == s.nchunks && s.ref.planes)
         return DST_OK;
-    for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats})
+    for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats, (void *)s.ref.partials})
         if (b)
             HIP_TRY(ctx, hipFree(b));
     s.ref.planes = nullptr;
     s.ref.hot_planes = nullptr;
     s.ref.hot_sites = nullptr;
     s.ref.stats = nullptr;
+    s.ref.partials = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_planes, s.nchunks * sizeof(uint4)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_sites, s.nchunks * kChunkSites * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 8 * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&s.ref.partials, s.nchunks * 16 * sizeof(uint32_t)));
     s.ref.nchunks = s.nchunks;
     return DST_OK;
 }
@@ -146,7 +148,6 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         }
         if (rc)
             return rc;
-        HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 8 * sizeof(uint64_t), stream));
         HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (n + 1) * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_hot, 0, (n + 1) * sizeof(uint32_t), stream));
         HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream));
@@ -390,7 +391,6 @@ int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     int rc_alloc = alloc_ref(ctx, s);
     if (rc_alloc)
         return rc_alloc;
-    HIP_TRY(ctx, hipMemsetAsync(s.ref.stats, 0, 8 * sizeof(uint64_t), stream));
     HIP_TRY(ctx, launch_ref_sample(s, stream));
     HIP_TRY(ctx, launch_hot_list(s, stream));
     HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));

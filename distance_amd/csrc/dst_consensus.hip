@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const ui
                                                          uint32_t len, uint32_t nchunks, uint32_t npad,
                                                          uint32_t samples, uint4 *__restrict__ ref_planes,
                                                          uint4 *__restrict__ hot_planes,
-                                                         unsigned long long *__restrict__ stats)
+                                                         uint32_t *__restrict__ partials)
 {
     // GROUPS groups of 128 threads, thread = (site, every GROUPS-th sample), UNR sampled records per round: their
     // loads are issued together (one record at a time this kernel was a chain of 128 memory latencies on one block
@@ -168,28 +168,49 @@ __global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const ui
         cdev += __shfl_xor(cdev, o);
         cdev2 += __shfl_xor(cdev2, o);
     }
-    if ((b & 63) == 0) {
-        atomicAdd(&stats[0], (unsigned long long)__builtin_popcountll(known));
-        atomicAdd(&stats[1], (unsigned long long)dev);
-        atomicAdd(&stats[2], (unsigned long long)dev2);
-        atomicAdd(&stats[4], (unsigned long long)__builtin_popcountll(hot_mask));
-        atomicAdd(&stats[5], (unsigned long long)__builtin_popcountll(known_hot));
-        atomicAdd(&stats[6], (unsigned long long)cdev);
-        atomicAdd(&stats[7], (unsigned long long)cdev2);
+    // this wave's share of the statistics (two per chunk, summed by hot_list_kernel: no same-address atomics)
+    if ((b & 63u) == 0) {
+        const uint32_t mine[8] = {(uint32_t)__builtin_popcountll(known), dev, dev2, 0u, (uint32_t)__builtin_popcountll(hot_mask),
+                                  (uint32_t)__builtin_popcountll(known_hot), cdev, cdev2};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            partials[((size_t)c * 2 + wave) * 8 + k] = mine[k];
     }
-    if (c == 0 && b == 0)
-        stats[3] = samples;
 }
 
 // ascending list of the hot sites (one block; nchunks is at most a few ten thousand)
 __global__ __launch_bounds__(1024) void hot_list_kernel(const uint4 *__restrict__ hot_planes, uint32_t nchunks,
-                                                        uint32_t *__restrict__ hot_sites)
+                                                        uint32_t *__restrict__ hot_sites,
+                                                        const uint32_t *__restrict__ partials, uint32_t samples,
+                                                        unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t base;
+    __shared__ unsigned long long sums[16][8];
+    {   // the sample's statistics: the chunks' shares (ref_sample_kernel) summed
+        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t c = threadIdx.x; c < 2 * nchunks; c += 1024)   // two shares per chunk
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                acc[k] += partials[(size_t)c * 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                acc[k] += __shfl_xor(acc[k], o);
+            if ((threadIdx.x & 63u) == 0)
+                sums[threadIdx.x >> 6][k] = acc[k];
+        }
+    }
     if (threadIdx.x == 0)
         base = 0;
     __syncthreads();
+    if (threadIdx.x < 8) {
+        unsigned long long t = 0;
+        for (int wv = 0; wv < 16; ++wv)
+            t += sums[wv][threadIdx.x];
+        stats[threadIdx.x] = threadIdx.x == 3 ? samples : t;
+    }
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 1024) {
         const uint32_t c = c0 + threadIdx.x;
         const uint4 m = c < nchunks ? hot_planes[c] : make_uint4(0, 0, 0, 0);
@@ -286,15 +307,27 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
     const size_t ps = (size_t)nchunks * npad;
     uint32_t run = 0;
     const uint32_t base0 = (FILL && live) ? rec[r] : 0u;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
+    // the planes of the NEXT step are loaded before this step's entries are written out (a wave walks its records'
+    // chunks one step after the other: without this every step waits a full memory latency)
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 nA = zero4, nG = zero4, nC = zero4, nT = zero4;
+    auto load_step = [&](uint32_t c0) {
         const uint32_t c = c0 + cl;
-        uint4 A = make_uint4(0, 0, 0, 0), G = A, C = A, T = A, d = A, rA = A, rG = A, rC = A, rT = A;
         if (live && c < nchunks) {
             const size_t at = (size_t)c * npad + r;
-            A = planes[PL_A * ps + at];
-            G = planes[PL_G * ps + at];
-            C = planes[PL_C * ps + at];
-            T = planes[PL_T * ps + at];
+            nA = planes[PL_A * ps + at];
+            nG = planes[PL_G * ps + at];
+            nC = planes[PL_C * ps + at];
+            nT = planes[PL_T * ps + at];
+        }
+    };
+    load_step(0);
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
+        const uint32_t c = c0 + cl;
+        uint4 A = nA, G = nG, C = nC, T = nT, d = zero4, rA = zero4, rG = zero4, rC = zero4, rT = zero4;
+        if (c0 + 8 < nchunks)
+            load_step(c0 + 8);
+        if (live && c < nchunks) {
             rA = ref_planes[c];
             rG = ref_planes[nchunks + c];
             rC = ref_planes[2 * (size_t)nchunks + c];
@@ -1117,7 +1150,7 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
     hipLaunchKernelGGL(ref_sample_kernel<false>, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), nullptr, 0, (uint32_t)set.n, (uint32_t)set.len,
                        (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes, set.ref.hot_planes,
-                       reinterpret_cast<unsigned long long *>(set.ref.stats));
+                       set.ref.partials);
     return hipGetLastError();
 }
 
@@ -1126,14 +1159,15 @@ hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, co
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, kRefSamples);
     hipLaunchKernelGGL(ref_sample_kernel<true>, dim3((unsigned)set.nchunks), dim3(1024), 0, stream, nullptr, d_codes, row_stride,
                        (uint32_t)set.n, (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
-                       set.ref.hot_planes, reinterpret_cast<unsigned long long *>(set.ref.stats));
+                       set.ref.hot_planes, set.ref.partials);
     return hipGetLastError();
 }
 
 hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream)
 {
     hipLaunchKernelGGL(hot_list_kernel, dim3(1), dim3(1024), 0, stream, set.ref.hot_planes, (uint32_t)set.nchunks,
-                       set.ref.hot_sites);
+                       set.ref.hot_sites, set.ref.partials, (uint32_t)std::min<size_t>(set.n, kRefSamples),
+                       reinterpret_cast<unsigned long long *>(set.ref.stats));
     return hipGetLastError();
 }
 

@@ -63,6 +63,7 @@ struct ConsensusRef {             // the reference sequence, sampled from the se
     uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records'); N past len
     uint4 *hot_planes = nullptr;  // [nchunks] bit = 1: a hot site (kHotPermille), handed to the dense kernels by the hybrid path
     uint32_t *hot_sites = nullptr;  // [n_hot] the hot sites, ascending
+    uint32_t *partials = nullptr;   // [nchunks][2][8] every chunk's two shares of `stats` (summed by hot_list_kernel)
     // device: {known sites, sum of deviants, sum of deviants^2, sample size, hot sites, known hot sites,
     //          sum of deviants over the cold sites, sum of deviants^2 over the cold sites}
     uint64_t *stats = nullptr;
