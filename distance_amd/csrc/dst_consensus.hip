@@ -14,15 +14,17 @@
 // pairwise, and for low-diversity alignments (SARS-CoV-2-like: ~65 differing sites of 30,000 per record)
 // it touches a few columns per row.  The pair kernel is then bound by WRITING the N^2/2 results:
 //
-//   ref_sample_kernel   per-site plurality code over a sample of records -> the reference c
-//   index_kernel        per record: ascending list of (site, nibble) where it differs from c; and the
-//                       same entries bucketed by (site, panel of 2,048 column records)
+//   ref_sample_kernel   per-site plurality code over a sample of records -> the reference c (from the planes, or
+//                       from the byte matrix BEFORE the pack, which then counts the list lengths on its way)
+//   index_kernel        per record: ascending list of (site, nibble) where it differs from c
 //   scan kernels        exclusive scan of the list lengths -> CSR offsets
+//   site_bucket_kernel  the same entries by (panel of 2,048 column records, site): 32-byte lookup-table entries that
+//                       hold the bucket itself, assembled per (panel, 1,024 sites) in LDS from the lists
 //   aconst_kernel       A_k(record), packed like the accumulators
 //   consensus_pair_kernel  one block = a few rows x one column panel: the rows' lists are joined with the
 //                       site buckets of the panel, h_k goes into LDS accumulators (ds_add_u32), then one
 //                       coalesced pass adds the per-record constants, finalises (f64, reference operation
-//                       order) and stores in canonical order
+//                       order) and stores in canonical order (nontemporal: written once, never read)
 //   site_hist_kernel    exact per-site base counts for consensus() itself (dst_consensus)
 //
 // Integer adds only (order-independent, exact); two 16-bit tallies share one 32-bit accumulator when the
@@ -742,18 +744,22 @@ __device__ __forceinline__ void store_result2(int64_t *p, int64_t a, int64_t b)
 // One block = rows [i0, i1) x one panel of up to kPanelCols column records; the rows go through kAccRows at a
 // time (a "batch"; their lists are adjacent in the CSR, so a batch is one run of entries).  512 threads in two
 // roles that work on consecutive batches at the same time, with the accumulators double-buffered in LDS:
-//   event waves (4): A) lane k takes entry k of the batch's lists: (site, reference class, nibble) -> the
-//      panel's bucket of that site from the lookup table (one 8-byte load) -> the bucket's first INL column
-//      entries (16-byte loads; buckets start on 16-byte boundaries);  B) every candidate event (column record,
-//      nibble) gets h_k from the table in LDS and goes into the (row, column) accumulators with ds_add_u32.
-//      Buckets larger than INL are shared out over the wave (scan of the sizes + search by shuffles);
-//      batches with more than 256 entries run extra slices.  No barrier inside A/B.
-//   output waves (4): C) every thread walks its column PAIRS (16-byte stores) for each row of the PREVIOUS
-//      batch: accumulator + A(column) + A(row) + F, unpack, finalise, store in canonical order; touched
-//      accumulators are reset on the way.  A(column) stays in registers for the whole tile.
+//   event waves (EW): A) lane k takes entry k of the batch's lists: (site, reference class, nibble) -> the 32-byte
+//      lookup-table entry of (panel, site), which IS the bucket: its size and up to 15 column entries (record in the
+//      panel | nibble), or 13 and the place of the others;  B) every candidate event (column record, nibble) gets
+//      h_k from the table in LDS and goes into the (row, column) accumulators with ds_add_u32.  What a larger bucket
+//      holds beyond the inline entries is shared out over the wave (scan of the sizes + search by shuffles); batches
+//      with more entries than the event lanes run extra slices.  The two dependent loads (entry, table entry) are
+//      software-pipelined in registers across batches.  No barrier inside A/B.
+//   output waves (8 - EW): C) for each row of the PREVIOUS batch every thread walks its column PAIRS (16-byte
+//      nontemporal stores): accumulator + A(column) + A(row) + F, unpack, finalise, store in canonical order; touched
+//      accumulators are reset on the way.
 // One barrier per batch.  Why two roles: gfx950 counts loads and stores in ONE in-order counter (vmcnt), so a
 // wave that has just issued its result stores cannot consume a younger load before those stores have
 // landed in HBM; the event waves' chains of dependent random loads never queue behind a store this way.
+// Why nontemporal stores: left to the default policy the 10 GB result stream of a 50,000-record launch flows through
+// the L2 and evicts the panel's lookup table the event waves gather from (FETCH_SIZE 0.88 GB -> 0.15 GB per launch,
+// raw 3.2 -> 2.5 ms; profiles/r02).
 template <int FAM, bool WIDE, int OUT, int EW>
 __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void consensus_pair_kernel(
     const uint32_t *__restrict__ row_off, const uint32_t *__restrict__ row_ent,

@@ -1,6 +1,15 @@
 #!/bin/bash
 # Measurement builds of the consensus pair kernel: tools/variants.sh name "-DMACRO ..." [name "-D..."]...
-# -> build/variants/libdistance_hip_<name>.so (select with DST_LIB_PATH).  Only dst_consensus.hip is rebuilt.
+# -> build/variants/libdistance_hip_<name>.so (select with DST_LIB_PATH; tools/variants_run.sh / variants_prof.sh /
+# variants_calib.sh run cbench / rocprofv3 / calibrate on each).  Only dst_consensus.hip is rebuilt.
+# Knobs (all compiled out of the product build; what each one answered is in DESIGN.md 3b):
+#   -DDST_DBG_NO_EVENTS     event waves idle: the output phase alone (the store floor)
+#   -DDST_DBG_NO_STORE      results computed, not stored: the event side + skeleton alone
+#   -DDST_DBG_NO_APPLY      event loads issued, LDS atomics skipped
+#   -DDST_DBG_PLAIN_STORES  default-policy stores instead of nontemporal ones
+#   -DDST_DBG_OLDMAP        panel-relative column mapping for every family (no address-aligned quarters)
+#   -DDST_DBG_EVWAVES=k     k event waves + 8-k output waves for every launch
+#   -DDST_DBG_RB=k          k rows per batch
 set -e
 cd "$(dirname "$0")/../distance_amd/csrc"
 mkdir -p ../../build/variants
