@@ -351,15 +351,41 @@ def main():
     # writes a contiguous range of the canonical order.  That is how the CLI runs N GPUs (one context, one D2H stream
     # and one formatter pipeline per GPU; the ordered writer takes the slabs in rank order).
     if args.exchange == "none":
-        bounds, offsets = slab_layout(n, world, square=True)
+        # A rank that starts at row r0 pairs its rows with records r0.. only, so it uploads (packs, indexes) records
+        # [r0, n) as a set of their own: row i of the sub-triangle is row r0 + i of the whole one, pair for pair.  The
+        # per-record preparation is what does not shrink with N, so the row ranges are cut to make
+        # prep x (records a rank holds) + pair time x (its pairs) equal over the ranks, from a timed probe.
+        def run_range(r0, r1, out):
+            if r1 <= r0 or r0 >= n - 1:
+                return                      # no rows (or only the last record, which has no pair of its own)
+            sub = codes[r0:]
+            eng.upload_device(0, sub.data_ptr(), n - r0, L, codes.stride(0), None, stream)
+            eng.run_square_device(measure, 0, r1 - r0, out.data_ptr(), out.numel() * 8, stream=stream)
+
+        eq_bounds, eq_offs = slab_layout(n, world, square=True)
+        probe_out = torch.empty(max(eq_offs[rank + 1] - eq_offs[rank], 1), dtype=out_dtype, device=dev)
+        t_all = 0.0
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_range(eq_bounds[rank], eq_bounds[rank + 1], probe_out)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+        pair_s = eng.last_kernel_ms()["pair_ms"] * 1e-3
+        held, mine = n - eq_bounds[rank], max(eq_offs[rank + 1] - eq_offs[rank], 1)
+        tt = torch.tensor([max(t_all - pair_s, 0.0) / held, pair_s / mine], dtype=torch.float64,
+                          device=dev if not args.rehearse_gloo else "cpu")
+        dist.all_reduce(tt)
+        prep_per_record, s_per_pair = float(tt[0].item()) / world, float(tt[1].item()) / world
+        del probe_out
+        bounds = balanced_bounds(n, world, prep_per_record, s_per_pair)
+        offsets = [da.square_row_start(n, b) for b in bounds]
         r0, r1 = bounds[rank], bounds[rank + 1]
         my_pairs = offsets[rank + 1] - offsets[rank]
         local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
 
         def step():
-            eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
-            if my_pairs:
-                eng.run_square_device(measure, r0, r1, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+            run_range(r0, r1, local_out)
 
         for _ in range(args.warmup):
             step()
@@ -401,13 +427,15 @@ def main():
                 "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order, "
                                        f"{world} contiguous ranges, each in its rank's HBM)",
                            "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs, "path": used,
-                           "partition": f"{world} contiguous row ranges of equal pair count; no collective in the data path "
+                           "partition": f"{world} contiguous row ranges, rows {bounds}: cut so that preparation x records held "
+                                        f"({prep_per_record * 1e9:.1f} ns per record, measured) + pair time x pairs "
+                                        f"({s_per_pair * 1e12:.2f} ps per pair, measured) is equal over the ranks; a rank uploads only "
+                                        "the records from its first row on; no collective in the data path "
                                         "(--exchange gather adds the RCCL send/recv of every slab to rank 0)",
                            "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
-                           "note": "strong scaling of a step whose per-rank share of the pairs shrinks with N while the pack "
-                                   "and the difference lists of the WHOLE set are rebuilt by every rank each step "
-                                   "(kernels_ms.pack + lists_and_constants): that replicated part bounds the speed-up "
-                                   "(DESIGN.md 6)",
+                           "note": "strong scaling of a step whose per-rank share of the pairs shrinks with N while the rank that "
+                                   "owns row 0 still packs and indexes the WHOLE set each step (kernels_ms.pack + "
+                                   "lists_and_constants): that part bounds the speed-up (DESIGN.md 6)",
                            "variant": args.variant},
                 "roofline": roofline(measure, used, k_ms, my_pairs),
                 "kernels_ms": {"rank": 0, "pack": float(np.mean(pack_ms)), "pair": k_ms,
@@ -600,6 +628,43 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
+
+
+def balanced_bounds(n: int, world: int, prep_per_record: float, s_per_pair: float) -> list[int]:
+    """Row bounds b[0] = 0 .. b[world] = n with prep_per_record * (n - b[k]) + s_per_pair * pairs(rows b[k]..b[k+1])
+    equal over the ranks (bisection on the common time; a rank holds the records from its first row on)."""
+    total = n * (n - 1) // 2
+
+    def cut(T):
+        b = [0]
+        for _ in range(world):
+            x = b[-1]
+            budget = (T - prep_per_record * (n - x)) / max(s_per_pair, 1e-18)
+            if budget < 0:
+                return None
+            target = da.square_row_start(n, x) + int(budget)
+            lo, hi = x, n                       # largest row r with row_start(r) <= target
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if da.square_row_start(n, mid) <= target:
+                    lo = mid
+                else:
+                    hi = mid
+            b.append(lo if target < total else n)
+        return b if b[-1] >= n - 1 else None
+
+    lo_t, hi_t = 0.0, prep_per_record * n + s_per_pair * total + 1e-9
+    for _ in range(60):
+        mid = 0.5 * (lo_t + hi_t)
+        if cut(mid) is None:
+            lo_t = mid
+        else:
+            hi_t = mid
+    b = cut(hi_t)
+    b[-1] = n
+    for k in range(1, world):                   # monotone, inside [0, n]
+        b[k] = min(max(b[k], b[k - 1]), n)
+    return b
 
 
 def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream, first_row: int = 0) -> dict:
