@@ -683,6 +683,8 @@ constexpr bool aligned_output()
 {
 #ifdef DST_DBG_OLDMAP
     return false;
+#elif defined(DST_DBG_ALIGN_JC69)
+    return Pack<FAM, WIDE>::W == 1;
 #else
     return Pack<FAM, WIDE>::W == 1 && OUT != DST_JC69;
 #endif
