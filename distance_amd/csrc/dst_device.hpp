@@ -59,13 +59,20 @@ __device__ __forceinline__ double dst_log(double x)
 // 1/(2d) > 2^-25 ulp away from every midpoint between adjacent doubles (the difference is a non-zero integer over
 // 2d in units of an ulp), and q + (n - d q) y misses n/d by less than 2^-45 ulp.  d == 0 (no site where both records
 // are known: NaN or inf) and larger tallies take the division.
+// 1/b to ~2^-46 for an integer 0 < b < 2^24: the f32 reciprocal and one Newton step.  With it div_by(a, b, y) is
+// RN(a/b) for every integer a < 2^24 (the argument above fin_raw) — not for other numerators.
+__device__ __forceinline__ double rcp_int24(double b)
+{
+    const double y0 = (double)__builtin_amdgcn_rcpf((float)b);
+    return fma(y0, fma(-b, y0, 1.0), y0);
+}
+
 __device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
 {
     const double nd = (double)n, dd = (double)d;
     if (d == 0 || (n | d) >> 24)
         return nd / dd;
-    const double y0 = (double)__builtin_amdgcn_rcpf((float)d);
-    const double y = fma(y0, fma(-dd, y0, 1.0), y0);
+    const double y = rcp_int24(dd);
     const double q = nd * y;
     return fma(fma(-dd, q, nd), y, q);
 }
@@ -99,7 +106,8 @@ __device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_
 {
     if (count_L == 0)
         return fin_k80_plain(count_L, ts, tv);
-    const double L = (double)count_L, inv_L = 1.0 / L;
+    // ts, tv <= count_L are integers: below 2^24 the quotients need no real division (rcp_int24)
+    const double L = (double)count_L, inv_L = count_L >> 24 ? 1.0 / L : rcp_int24(L);
     const double P = div_by((double)ts, L, inv_L);
     const double Q = div_by((double)tv, L, inv_L);
     return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
@@ -131,8 +139,8 @@ __device__ __attribute__((noinline)) double fin_tn93_plain(uint32_t count_L, uin
     return d;
 }
 
-// The same values with 7 divisions instead of 18: the quotients over L, count_L, g_R and g_Y share one
-// reciprocal each (div_by).  The integer sums are exact in f64 (< 2^53), so adding them as integers first gives
+// The same values with 5 divisions instead of 18: the quotients over L, count_L, g_R and g_Y share one
+// reciprocal each (div_by), and the two integer divisors take theirs from rcp_int24.  The integer sums are exact in f64 (< 2^53), so adding them as integers first gives
 // the reference's values.
 __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
                                            uint32_t count_P2, uint4 qc, uint4 tc)
@@ -141,7 +149,10 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
                    sC = (uint64_t)tc.w + qc.w;
     if (count_L == 0 || sA + sG == 0 || sC + sT == 0)
         return fin_tn93_plain(count_L, count_d, count_P1, count_P2, qc, tc);
-    const double L = (double)(sA + sT + sG + sC), inv_L = 1.0 / L;
+    // the base-frequency and P1 / P2 / Q quotients are integers over integers: below 2^24 they need no real division
+    const uint64_t sL = sA + sT + sG + sC;
+    const bool small = ((sL | (uint64_t)count_L | (uint64_t)count_d) >> 24) == 0;
+    const double L = (double)sL, inv_L = small ? rcp_int24(L) : 1.0 / L;
     const double g_A = div_by((double)sA, L, inv_L);
     const double g_C = div_by((double)sC, L, inv_L);
     const double g_G = div_by((double)sG, L, inv_L);
@@ -152,7 +163,7 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     const double k1 = div_by(2.0 * g_A * g_G, g_R, inv_R);
     const double k2 = div_by(2.0 * g_T * g_C, g_Y, inv_Y);
     const double k3 = 2.0 * (g_R * g_Y - div_by(g_A * g_G * g_Y, g_R, inv_R) - div_by(g_T * g_C * g_R, g_Y, inv_Y));
-    const double cL = (double)count_L, inv_cL = 1.0 / cL;
+    const double cL = (double)count_L, inv_cL = small ? rcp_int24(cL) : 1.0 / cL;
     const double P1 = div_by((double)count_P1, cL, inv_cL);
     const double P2 = div_by((double)count_P2, cL, inv_cL);
     const double Q = div_by((double)(count_d - (count_P1 + count_P2)), cL, inv_cL);
