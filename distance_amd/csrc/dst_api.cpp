@@ -21,6 +21,7 @@ std::string g_create_err;
 std::mutex g_create_mu;
 
 int publish_prep(dst_ctx *ctx, hipStream_t stream);
+int wait_for_other_runs(dst_ctx *ctx, hipStream_t stream);
 
 int fail(dst_ctx *ctx, int status, const std::string &msg)
 {
@@ -88,6 +89,7 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.npad = npad;
     s.loaded = false;
     s.have_counts = false;
+    s.lean = false;
     s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
     s.ref.valid = s.rec.valid = s.site.valid = s.rec.pre_valid = false;
     s.aconst_family = -1;
@@ -214,11 +216,25 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
         s.ref.valid = true;
         const double max_dev = kListsMaxDeviation * (double)len * (double)std::min<size_t>(n, kRefSamples);
         s.rec.pre_valid = (double)s.ref.h_stats[1] <= (double)(unsigned long long)max_dev;   // the kernel's own test
+        s.lean = s.rec.pre_valid;   // ... which also made it skip the four derived planes
         s.rec.pre_epoch = s.epoch;
         s.rec.pre_total_cold = totals[0];
         s.rec.pre_total_hot = totals[1];
     }
     return DST_OK;
+}
+
+// the dense pair kernels read all eight planes: build the four derived ones of a set that was packed lean
+int ensure_derived(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
+{
+    if (!s.lean)
+        return DST_OK;
+    int rc = wait_for_other_runs(ctx, stream);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, launch_derive(s, stream));
+    s.lean = false;
+    return publish_prep(ctx, stream);
 }
 
 int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
@@ -752,6 +768,11 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         return DST_OK;
     }
     ctx->last_path = DST_PATH_DENSE;
+    rc = ensure_derived(ctx, cols, stream);
+    if (!rc && &rows != &cols)
+        rc = ensure_derived(ctx, rows, stream);
+    if (rc)
+        return rc;
     const TileShape ts = tile_shape(measure, ctx->variant);
     uint32_t nblocks = 0;
     const BlockDesc *d_blocks = nullptr;

@@ -275,10 +275,22 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
             const size_t at = ((size_t)(s >> 7) * npad + r) * 4 + ((s >> 5) & 3u);
             const uint32_t bit = s & 31u, ow = k >> 5, ob = k & 31u;
 #pragma unroll
-            for (int p = 0; p < PL_COUNT; ++p) {
+            for (int p = 0; p <= PL_T; ++p) {   // the base planes; the source set may be lean (no other planes)
                 const uint32_t v = (planes32[p * ps + at] >> bit) & 1u;
                 o[p][ow] = (o[p][ow] & ~(1u << ob)) | (v << ob);
             }
+        }
+        // K, X1, X0, CL of the gathered columns from their base bits (what pack_kernel's split4 computes)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t A = o[PL_A][w], G = o[PL_G][w], C = o[PL_C][w], T = o[PL_T][w];
+            const uint32_t pur = A | G, pyr = C | T;
+            const uint32_t K = (A ^ G ^ C ^ T) & ~((A & G) | (C & T));
+            const uint32_t X1 = pyr & ~pur;
+            o[PL_K][w] = K;
+            o[PL_X1][w] = X1;
+            o[PL_CL][w] = X1 | (pur & ~pyr);
+            o[PL_X0][w] = K & (G | T);
         }
     }
 #pragma unroll

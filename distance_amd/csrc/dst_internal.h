@@ -110,6 +110,8 @@ struct DeviceSet {
     size_t n = 0, len = 0, nchunks = 0, npad = 0;
     bool loaded = false;
     bool have_counts = false;
+    bool lean = false;            // only the four base planes are stored (a low-diversity set headed for the consensus path):
+                                  // the dense pair kernels' other planes are derived on demand (ensure_derived)
     uint64_t epoch = 0;           // bumped by every upload: stale consensus indexes are rebuilt
     // consensus path
     ConsensusRef ref;
@@ -229,6 +231,7 @@ struct PackLists {
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
+hipError_t launch_derive(const DeviceSet &set, hipStream_t stream);   // planes K, X1, X0, CL of a lean set from its base planes
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
 hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,
                            void *d_out, hipStream_t stream);

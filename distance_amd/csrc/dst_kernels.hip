@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
     // The consensus path's first pass, for free: how many sites of this (record, chunk) differ from the reference
     // sequence (sampled from the bytes before this kernel).  Cold and hot sites apart: the hybrid path leaves the hot
     // ones out of the lists.  Skipped when the sample says the set is too diverse for lists.
-    if (lists.ref_planes && lists.stats[1] <= lists.max_dev_sum) {
+    const bool low_diversity = lists.ref_planes && lists.stats[1] <= lists.max_dev_sum;
+    if (low_diversity) {
         uint32_t cold = 0, hot = 0;
         if (s < n) {
             const uint4 h4 = lists.hot_planes[c];
@@ -164,9 +165,42 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                 atomicAdd(&lists.cnt_hot[s], hot);
         }
     }
+    // A set headed for the consensus path is stored lean: the K, X1, X0 and CL planes are functions of the four base
+    // planes (derive_planes below) that only the dense pair kernels read; derive_kernel builds them if one ever runs.
 #pragma unroll
     for (int p = 0; p < PL_COUNT; ++p)
-        planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+        if (p <= PL_T || !low_diversity)
+            planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+}
+
+// K, X1, X0, CL of 32 sites from their base planes (for the 17 valid codes: split4 above computes the same bits)
+__device__ __forceinline__ void derive_planes(uint32_t A, uint32_t G, uint32_t C, uint32_t T, uint32_t &K, uint32_t &X1,
+                                              uint32_t &X0, uint32_t &CL)
+{
+    const uint32_t pur = A | G, pyr = C | T;
+    K = (A ^ G ^ C ^ T) & ~((A & G) | (C & T));   // exactly one base
+    X1 = pyr & ~pur;
+    CL = X1 | (pur & ~pyr);
+    X0 = K & (G | T);
+}
+
+// the four derived planes of a set that was packed lean
+__global__ __launch_bounds__(256) void derive_kernel(uint4 *__restrict__ planes, size_t per_plane)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_plane)
+        return;
+    const uint4 A = planes[PL_A * per_plane + i], G = planes[PL_G * per_plane + i], C = planes[PL_C * per_plane + i],
+                T = planes[PL_T * per_plane + i];
+    uint4 K, X1, X0, CL;
+    derive_planes(A.x, G.x, C.x, T.x, K.x, X1.x, X0.x, CL.x);
+    derive_planes(A.y, G.y, C.y, T.y, K.y, X1.y, X0.y, CL.y);
+    derive_planes(A.z, G.z, C.z, T.z, K.z, X1.z, X0.z, CL.z);
+    derive_planes(A.w, G.w, C.w, T.w, K.w, X1.w, X0.w, CL.w);
+    planes[PL_K * per_plane + i] = K;
+    planes[PL_X1 * per_plane + i] = X1;
+    planes[PL_X0 * per_plane + i] = X0;
+    planes[PL_CL * per_plane + i] = CL;
 }
 
 // {A,T,G,C} counts by code (src/fastaio.rs:53-66): a known base is K & its own bit-plane.
@@ -181,9 +215,13 @@ __global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ p
     const size_t ps = (size_t)nchunks * npad;
     for (uint32_t c = 0; c < nchunks; ++c) {
         const size_t at = (size_t)c * npad + s;
-        const uint4 K = planes[PL_K * ps + at];
         const uint4 A = planes[PL_A * ps + at], G = planes[PL_G * ps + at];
         const uint4 C = planes[PL_C * ps + at], T = planes[PL_T * ps + at];
+        uint4 K;   // exactly one base: the K plane's bits, computed (a lean set has no K plane)
+        K.x = (A.x ^ G.x ^ C.x ^ T.x) & ~((A.x & G.x) | (C.x & T.x));
+        K.y = (A.y ^ G.y ^ C.y ^ T.y) & ~((A.y & G.y) | (C.y & T.y));
+        K.z = (A.z ^ G.z ^ C.z ^ T.z) & ~((A.z & G.z) | (C.z & T.z));
+        K.w = (A.w ^ G.w ^ C.w ^ T.w) & ~((A.w & G.w) | (C.w & T.w));
         a += __builtin_popcount(K.x & A.x) + __builtin_popcount(K.y & A.y) +
              __builtin_popcount(K.z & A.z) + __builtin_popcount(K.w & A.w);
         t += __builtin_popcount(K.x & T.x) + __builtin_popcount(K.y & T.y) +
@@ -582,6 +620,13 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
                        d_first_bad, aligned16, lists ? *lists : none);
+    return hipGetLastError();
+}
+
+hipError_t launch_derive(const DeviceSet &set, hipStream_t stream)
+{
+    const size_t per_plane = set.nchunks * set.npad;
+    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, stream, set.planes, per_plane);
     return hipGetLastError();
 }
 

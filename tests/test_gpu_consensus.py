@@ -339,3 +339,28 @@ def test_auto_takes_the_hybrid_for_structured_data(eng):
             assert eng.last_path() == "hybrid"
     assert torch.equal(out["auto"].view(torch.int64), out["dense"].view(torch.int64))      # every bit of every distance
     eng.set_path("auto")
+
+
+def test_a_lean_set_still_serves_every_path(eng):
+    """A low-diversity set uploaded while the path is not forced dense is stored lean (four base planes, the list
+    lengths counted by the pack, the reference sampled from the bytes).  Whatever runs on it afterwards — the lists,
+    the dense kernels (which need the derived planes built after all), tn93's base counts, the hybrid's hot columns —
+    must give the same bits as a set that was packed for the dense path from the start."""
+    codes = np.concatenate([low_diversity(2600, 6000, 91), clade_alignment(400, 6000, 92)])   # 0.5 n^2 L = 2.7e10
+    ref = da.Engine(0)
+    ref.set_path("dense")
+    ref.upload(0, codes)
+    want = {m: ref.run_square(m, 0, 40) for m in ALL}
+    want_tallies = {m: ref.run_square(m, 5, 9, tallies=True) for m in ("raw", "k80", "tn93")}
+    ref.close()
+    for order in (("consensus", "dense", "hybrid"), ("dense", "hybrid", "consensus"), ("hybrid", "consensus", "dense")):
+        eng.set_path("auto")
+        eng.upload(0, codes)                         # lean: the path is open at upload time
+        for path in order:
+            eng.set_path(path)
+            for m in ALL:
+                got = eng.run_square(m, 0, 40)
+                assert np.array_equal(got, want[m], equal_nan=True), (order, path, m)
+            for m in want_tallies:
+                assert np.array_equal(eng.run_square(m, 5, 9, tallies=True), want_tallies[m]), (order, path, m)
+    eng.set_path("auto")
