@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
     if (s < n) {
         const uint32_t site0 = c * kChunkSites;
         const uint8_t *row = codes + (size_t)s * row_stride + site0;
-        const bool fast = aligned16 && site0 + kChunkSites <= len;
+        const bool fast = (aligned16 & 1) && site0 + kChunkSites <= len;
+        // the shifted path reads from 3 bytes before to 4 bytes after the chunk's 128: inside the matrix unless this
+        // is its very first chunk (and the matrix starts off a 4-byte boundary) or within 132 bytes of its end
+        const bool words = !fast && (size_t)s * row_stride + site0 + kChunkSites + 4 <= (size_t)(n - 1) * row_stride + len &&
+                           (s > 0 || c > 0 || (aligned16 & 2));
         uint32_t bad_at = 0xFFFFFFFFu;
         // the lane's whole 128-byte line at once: its eight 16-byte loads are in flight together, so the line is
         // consumed while it is still in the L1 (spread over the four words below it was fetched again and again)
@@ -101,6 +105,27 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                 const uint4 lo = in[2 * w], hi = in[2 * w + 1];
                 x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
                 x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+            } else if (words) {
+                // rows on any boundary (29,903- or 1,000-site records): aligned 4-byte loads around the 32 bytes and a
+                // funnel shift (v_alignbit) — byte loads cost 25x the aligned path
+                const uintptr_t a = reinterpret_cast<uintptr_t>(row) + 32u * w;
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(a & 3u) * 8u;
+                uint32_t d[9];
+#pragma unroll
+                for (int g = 0; g < 9; ++g)
+                    d[g] = p[g];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    x[g] = __builtin_amdgcn_alignbit(d[g + 1], d[g], sh);
+                    // the last chunk of a row: what lies past the row's end (the next row's bytes) becomes N
+                    const uint32_t first = site0 + 32u * w + 4u * g;
+                    if (first + 4 > len) {
+                        const uint32_t keep = first < len ? len - first : 0u;   // bytes of this word inside the row
+                        const uint32_t m = keep ? 0xFFFFFFFFu >> (32u - 8u * keep) : 0u;
+                        x[g] = (x[g] & m) | (0xF0F0F0F0u & ~m);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -605,7 +630,9 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream)
 {
     const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-    const int aligned16 = (reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0);
+    // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
+    const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
+                          (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);
     dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
