@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals, s.rec.pre_slots,
                     s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -148,6 +148,8 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
             HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_totals, 2 * sizeof(unsigned long long)));
             s.rec.pre_cap = n + 1;
         }
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&s.rec.pre_slots, &s.rec.pre_slots_cap, s.nchunks * s.npad * sizeof(uint4));
         if (rc)
             return rc;
         HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (n + 1) * sizeof(uint32_t), stream));
@@ -160,6 +162,7 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         pl.max_dev_sum = (unsigned long long)(kListsMaxDeviation * (double)len * (double)std::min<size_t>(n, kRefSamples));
         pl.cnt_cold = s.rec.pre_cold;
         pl.cnt_hot = s.rec.pre_hot;
+        pl.slots = s.rec.pre_slots;
     }
     HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
@@ -472,7 +475,8 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
     unsigned long long total = 0;
-    if (&s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch) {
+    const bool from_pack = &s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch;
+    if (from_pack) {
         // the pack counted the list lengths against this very reference: no pass over the planes, no round trip
         HIP_TRY(ctx, hipMemcpyAsync(s.rec.off, s.rec.pre_cold, (s.n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         total = s.rec.pre_total_cold;
@@ -498,8 +502,12 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
-    HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent, want_sites ? s.rec.col : nullptr,
-                              ctx->d_total, stream));
+    if (from_pack)   // the entries are in the pack's slots already
+        HIP_TRY(ctx, launch_slot_fill(s, refset.ref.planes, refset.ref.hot_planes, without_hot, s.rec.off, s.rec.ent,
+                                      want_sites ? s.rec.col : nullptr, stream));
+    else
+        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent,
+                                  want_sites ? s.rec.col : nullptr, ctx->d_total, stream));
     if (want_sites)
         HIP_TRY(ctx, launch_site_buckets(s, n_panels, d_ovf_n, stream));
     // runs queued on other streams wait for this on the device

@@ -414,6 +414,113 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
     }
 }
 
+// The fill pass from the pack's slots: same wave layout and output as index_kernel<true> (8 records x 8 chunks per
+// step, ascending site order), but a (record, chunk) is one 16-byte slot that already holds its entries — a quarter
+// of the four planes' bytes.  A chunk with more than kSlotEntries differences goes back to the planes.
+__global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict__ slots, const uint4 *__restrict__ planes,
+                                                        const uint4 *__restrict__ ref_planes,
+                                                        const uint4 *__restrict__ hot_planes, int without_hot, uint32_t n,
+                                                        uint32_t nchunks, uint32_t npad,
+                                                        const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
+                                                        uint16_t *__restrict__ rec_col)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t rl = lane & 7u, cl = lane >> 3;
+    const uint32_t r = wave * 8u + rl;
+    const bool live = r < n;
+    const size_t ps = (size_t)nchunks * npad;
+    uint32_t run = 0;
+    const uint32_t base0 = live ? rec_off[r] : 0u;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
+        const uint32_t c = c0 + cl;
+        const uint4 slot = nslot;
+        if (c0 + 8 < nchunks)
+            nslot = (live && c + 8 < nchunks) ? slots[(size_t)(c + 8) * npad + r] : zero4;
+        const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w};
+        const uint32_t cnt_all = slot.x & 0xFFu;
+        const bool big = cnt_all > kSlotEntries;
+        // entries this lane emits: from the slot, or (big) from the planes
+        uint32_t pc = 0;
+        uint4 A = zero4, G = zero4, C = zero4, T = zero4, d = zero4, rA = zero4, rG = zero4, rC = zero4, rT = zero4;
+        if (big) {
+            const size_t at = (size_t)c * npad + r;
+            A = planes[PL_A * ps + at];
+            G = planes[PL_G * ps + at];
+            C = planes[PL_C * ps + at];
+            T = planes[PL_T * ps + at];
+            rA = ref_planes[c];
+            rG = ref_planes[nchunks + c];
+            rC = ref_planes[2 * (size_t)nchunks + c];
+            rT = ref_planes[3 * (size_t)nchunks + c];
+            d.x = (A.x ^ rA.x) | (G.x ^ rG.x) | (C.x ^ rC.x) | (T.x ^ rT.x);
+            d.y = (A.y ^ rA.y) | (G.y ^ rG.y) | (C.y ^ rC.y) | (T.y ^ rT.y);
+            d.z = (A.z ^ rA.z) | (G.z ^ rG.z) | (C.z ^ rC.z) | (T.z ^ rT.z);
+            d.w = (A.w ^ rA.w) | (G.w ^ rG.w) | (C.w ^ rC.w) | (T.w ^ rT.w);
+            if (without_hot) {
+                const uint4 h = hot_planes[c];
+                d.x &= ~h.x;
+                d.y &= ~h.y;
+                d.z &= ~h.z;
+                d.w &= ~h.w;
+            }
+            pc = popc4(d);
+        } else {
+#pragma unroll
+            for (uint32_t k = 1; k <= kSlotEntries; ++k) {
+                const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                pc += (k <= cnt_all && !(without_hot && (e >> 14 & 1u))) ? 1u : 0u;
+            }
+        }
+        uint32_t incl = pc, up;
+        up = __shfl_up(incl, 8);
+        if (cl >= 1) incl += up;
+        up = __shfl_up(incl, 16);
+        if (cl >= 2) incl += up;
+        up = __shfl_up(incl, 32);
+        if (cl >= 4) incl += up;
+        const uint32_t tot = __shfl(incl, 56 + rl);
+        if (pc) {
+            uint32_t at = base0 + run + (incl - pc);
+            const uint16_t colv = (uint16_t)(r & (kPanelCols - 1u));
+            if (big) {
+                const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+                const uint32_t aw[4] = {A.x, A.y, A.z, A.w}, gw[4] = {G.x, G.y, G.z, G.w};
+                const uint32_t cw[4] = {C.x, C.y, C.z, C.w}, tw[4] = {T.x, T.y, T.z, T.w};
+                const uint32_t raw[4] = {rA.x, rA.y, rA.z, rA.w}, rgw[4] = {rG.x, rG.y, rG.z, rG.w};
+                const uint32_t rcw[4] = {rC.x, rC.y, rC.z, rC.w}, rtw[4] = {rT.x, rT.y, rT.z, rT.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t m = dw[w];
+                    while (m) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t nib = ((aw[w] >> bit) & 1u) << 3 | ((gw[w] >> bit) & 1u) << 2 |
+                                             ((cw[w] >> bit) & 1u) << 1 | ((tw[w] >> bit) & 1u);
+                        const uint32_t rnib = ((raw[w] >> bit) & 1u) << 3 | ((rgw[w] >> bit) & 1u) << 2 |
+                                              ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
+                        if (rec_col)
+                            rec_col[at] = colv;
+                        rec_ent[at++] = (c * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 1; k <= kSlotEntries; ++k) {
+                    const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    if (k <= cnt_all && !(without_hot && (e >> 14 & 1u))) {
+                        if (rec_col)
+                            rec_col[at] = colv;
+                        rec_ent[at++] = (c * kChunkSites + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
+                    }
+                }
+            }
+        }
+        run += tot;
+    }
+}
+
 // =============================================================================================
 // site buckets of a column set, from its difference lists
 // =============================================================================================
@@ -1210,6 +1317,15 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uin
     else
         hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
                            (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, rec_col, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
+                            uint32_t *rec_off, uint32_t *rec_ent, uint16_t *rec_col, hipStream_t stream)
+{
+    hipLaunchKernelGGL(slot_fill_kernel, dim3((unsigned)((set.n + 31) / 32)), dim3(256), 0, stream, set.rec.pre_slots, set.planes,
+                       ref_planes, hot_planes, without_hot ? 1 : 0, (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad,
+                       rec_off, rec_ent, rec_col);
     return hipGetLastError();
 }
 

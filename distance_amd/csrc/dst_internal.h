@@ -54,6 +54,7 @@ constexpr uint32_t kSiteBits = 25;         // record-list entries: site | refere
 constexpr uint32_t kSiteMask = (1u << kSiteBits) - 1;
 constexpr uint32_t kInlineEvents = 15;     // bucket entries held inside the 32-byte lookup-table entry
 constexpr uint32_t kInlineOverflowing = 13;  // ... of a larger bucket: its last word is where the rest are
+constexpr uint32_t kSlotEntries = 7;        // differences a (record, chunk) slot of the pack holds
 constexpr uint32_t kRefSamples = 512;      // records sampled for the reference sequence
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
@@ -78,6 +79,8 @@ struct RecordIndex {              // per record: the sites where it differs from
     uint16_t *col = nullptr;      // column sets: the entry's record within its panel (read by site_bucket_kernel)
     // list lengths counted by the pack itself against the set's own reference (cold sites / hot sites apart), with
     // their sums {cold, hot} — valid while pre_epoch == the set's epoch
+    uint4 *pre_slots = nullptr;   // [nchunks][npad] the entries themselves, by (record, chunk) (PackLists::slots)
+    size_t pre_slots_cap = 0;
     uint32_t *pre_cold = nullptr, *pre_hot = nullptr;
     unsigned long long *pre_totals = nullptr;
     size_t pre_cap = 0;
@@ -205,6 +208,9 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
                         uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total,
                         hipStream_t stream);
+// the same lists from the pack's slots (set.rec.pre_slots) instead of the planes; without_hot: leave the hot entries out
+hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
+                            uint32_t *rec_off, uint32_t *rec_ent, uint16_t *rec_col, hipStream_t stream);
 // a column set's site buckets from its lists (set.rec -> set.site); *ovf_total (zeroed by the caller) counts the
 // overflow entries placed in set.site.ent
 hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream);
@@ -227,6 +233,7 @@ struct PackLists {
     const unsigned long long *stats;           // the sample's statistics (device): [1] = sum of deviants
     unsigned long long max_dev_sum;            // count only while stats[1] <= this (high-diversity sets go dense anyway)
     uint32_t *cnt_cold, *cnt_hot;              // [n], zeroed
+    uint4 *slots;                              // [nchunks][npad] the differences of every (record, chunk), see pack_kernel
 };
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream);

@@ -168,28 +168,52 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
     const bool low_diversity = lists.ref_planes && lists.stats[1] <= lists.max_dev_sum;
     if (low_diversity) {
         uint32_t cold = 0, hot = 0;
+        // ... and the entries themselves, while the codes are in registers: one 16-byte slot per (record, chunk) —
+        // halfword 0 = differences in the chunk, then up to kSlotEntries of them in site order as
+        // site-in-chunk | class of the reference << 7 | nibble << 10 | hot << 14.  The fill pass reads these slots
+        // (1/4 of the planes it would read) and goes back to the planes only for a chunk with more differences.
+        uint32_t slot[4] = {0, 0, 0, 0};
         if (s < n) {
             const uint4 h4 = lists.hot_planes[c];
             const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w};
-            uint32_t d[4] = {0, 0, 0, 0};
+            uint32_t rw[4][4];
 #pragma unroll
             for (int p = 0; p <= PL_T; ++p) {
                 const uint4 r4 = lists.ref_planes[(size_t)p * nchunks + c];
-                const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    d[w] |= out[p][w] ^ rw[w];
+                rw[p][0] = r4.x; rw[p][1] = r4.y; rw[p][2] = r4.z; rw[p][3] = r4.w;
             }
+            uint32_t d[4], k = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
+                d[w] = (out[PL_A][w] ^ rw[PL_A][w]) | (out[PL_G][w] ^ rw[PL_G][w]) | (out[PL_C][w] ^ rw[PL_C][w]) |
+                       (out[PL_T][w] ^ rw[PL_T][w]);
                 cold += __builtin_popcount(d[w] & ~hw[w]);
                 hot += __builtin_popcount(d[w] & hw[w]);
             }
-            if (cold)
-                atomicAdd(&lists.cnt_cold[s], cold);
-            if (hot)
-                atomicAdd(&lists.cnt_hot[s], hot);
+            if (cold + hot) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t m = d[w];
+                    while (m && k < kSlotEntries) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t nib = ((out[PL_A][w] >> bit) & 1u) << 3 | ((out[PL_G][w] >> bit) & 1u) << 2 |
+                                             ((out[PL_C][w] >> bit) & 1u) << 1 | ((out[PL_T][w] >> bit) & 1u);
+                        const uint32_t rnib = ((rw[PL_A][w] >> bit) & 1u) << 3 | ((rw[PL_G][w] >> bit) & 1u) << 2 |
+                                              ((rw[PL_C][w] >> bit) & 1u) << 1 | ((rw[PL_T][w] >> bit) & 1u);
+                        const uint32_t cls = rnib == 8 ? 0u : rnib == 4 ? 1u : rnib == 2 ? 2u : rnib == 1 ? 3u : 4u;
+                        const uint32_t e = (32u * w + bit) | cls << 7 | nib << 10 | ((hw[w] >> bit) & 1u) << 14;
+                        ++k;   // halfword k of the slot
+                        slot[k >> 1] |= e << (16u * (k & 1u));
+                    }
+                }
+                slot[0] |= min(cold + hot, 255u);
+                atomicAdd(&lists.cnt_cold[s], cold);   // (adding 0 for an all-hot chunk is harmless)
+                if (hot)
+                    atomicAdd(&lists.cnt_hot[s], hot);
+            }
         }
+        lists.slots[(size_t)c * npad + s] = make_uint4(slot[0], slot[1], slot[2], slot[3]);
     }
     // A set headed for the consensus path is stored lean: the K, X1, X0 and CL planes are functions of the four base
     // planes (derive_planes below) that only the dense pair kernels read; derive_kernel builds them if one ever runs.
@@ -629,7 +653,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tal
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream)
 {
-    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
                           (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);
