@@ -14,11 +14,15 @@ set -e
 cd "$(dirname "$0")/../distance_amd/csrc"
 mkdir -p ../../build/variants
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function"
+SRC=${VARIANT_SRC:-dst_consensus}   # which translation unit gets the macros (dst_consensus or dst_kernels)
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
-  /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c dst_consensus.hip -o ../../build/variants/dst_consensus_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -no-hip-rt ../../build/obj/dst_kernels.o ../../build/variants/dst_consensus_$name.o \
-     ../../build/obj/dst_api.o ../../build/obj/dst_stream.o ../../build/obj/dst_host.o ../../build/obj/dst_gather.o \
+  /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c $SRC.hip -o ../../build/variants/${SRC}_$name.o
+  objs=""
+  for o in dst_kernels dst_consensus dst_api dst_stream dst_host dst_gather; do
+    if [ $o = $SRC ]; then objs="$objs ../../build/variants/${SRC}_$name.o"; else objs="$objs ../../build/obj/$o.o"; fi
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -no-hip-rt $objs \
      -o ../../build/variants/libdistance_hip_$name.so -L../../build/hipstub -lamdhip64 -ldl -Wl,-rpath,/opt/rocm/lib
   echo built $name
 done
