@@ -570,6 +570,8 @@ struct Slab {
     uint32_t *tallies = nullptr;  // page-locked (PinnedPool): the copy back runs at link speed
     size_t tallies_cap = 0;
     std::vector<TextBuf> text;            // formatted parts, in canonical order
+    char *gtext = nullptr;                // the whole slab's text, formatted on the GPU (page-locked, PinnedPool)
+    size_t gtext_len = 0, gtext_cap = 0;
 };
 
 struct Job {
@@ -580,6 +582,7 @@ struct Job {
     const Alignment *cols = nullptr;
     const uint32_t *row_counts = nullptr, *col_counts = nullptr;  // tn93 {A,T,G,C}
     size_t fmt_threads = 1;
+    bool gpu_text = false;            // the GPU writes the TSV lines itself (dst_text_*); the host only writes them out
 };
 
 // tallies -> TSV text, in canonical order, split over the formatting pool (-t)
@@ -747,6 +750,11 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
     std::vector<std::unique_ptr<Slab>> ready(slabs.size());
     Job fjob = job;
     fjob.fmt_threads = std::max<size_t>(1, job.fmt_threads / n_formatters);
+    size_t row_id_max = 0, col_id_max = 0;
+    for (const auto &id : job.rows->ids)
+        row_id_max = std::max(row_id_max, id.size());
+    for (const auto &id : job.cols->ids)
+        col_id_max = std::max(col_id_max, id.size());
 
     auto gpu_worker = [&](size_t g) {
         for (;;) {
@@ -762,6 +770,31 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
             s->re = slabs[k].second;
             const uint64_t pairs = job.square ? dst_square_row_start(job.cols->n, s->re) - dst_square_row_start(job.cols->n, s->rb)
                                               : (s->re - s->rb) * job.cols->n;
+            if (job.gpu_text) {
+                // ids + number + separators per line; a slab the device formatter declines (a value without a short
+                // text, a slab beyond its limits) is formatted on the host like before
+                size_t cap = 0, len = 0;
+                char *buf = reinterpret_cast<char *>(pool.acquire((size_t)pairs * (row_id_max + col_id_max + 34) + 64, &cap));
+                if (!buf)
+                    gpus[g].check(DST_ERR_NOMEM, "pinned host buffer");
+                const int trc = job.square ? dst_text_square(gpus[g].h, job.measure, s->rb, s->re, buf, cap, &len)
+                                           : dst_text_rect(gpus[g].h, job.measure, row_slot, col_slot, s->rb, s->re, 0, buf,
+                                                           cap, &len);
+                if (trc == DST_OK) {
+                    s->gtext = buf;
+                    s->gtext_len = len;
+                    s->gtext_cap = cap;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        ready[k] = std::move(s);
+                    }
+                    cv.notify_all();
+                    continue;
+                }
+                pool.release(reinterpret_cast<uint32_t *>(buf), cap);
+                if (trc != DST_ERR_STATE && trc != DST_ERR_ARG && trc != DST_ERR_CAPACITY)
+                    gpus[g].check(trc, "text");
+            }
             const size_t n_tallies = (size_t)pairs * w;
             s->tallies = pool.acquire(std::max<size_t>(n_tallies, 1) * 4, &s->tallies_cap);
             if (!s->tallies)
@@ -814,6 +847,10 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return ready[next_to_write] != nullptr; });
             s = std::move(ready[next_to_write]);
+        }
+        if (s->gtext) {
+            wr.write(s->gtext, s->gtext_len);
+            pool.release(reinterpret_cast<uint32_t *>(s->gtext), s->gtext_cap);
         }
         for (const TextBuf &part : s->text)
             wr.write(part.p.get(), part.len);
@@ -1035,6 +1072,22 @@ int main(int argc, char **argv)
         job.cols = &loaded.back();
         job.row_counts = measure == DST_TN93 ? counts[0].data() : nullptr;
         job.col_counts = measure == DST_TN93 ? counts.back().data() : nullptr;
+        // The TSV lines themselves come from the GPU (dst_text_*): it has the distances and the ids, the exact
+        // {:.12} conversion is integer arithmetic, and the host's formatter pool was what bounded a large run.
+        // DISTANCE_HOST_FORMAT=1 keeps the host formatter (the two give the same bytes: tests/test_gpu_cli.py).
+        job.gpu_text = std::getenv("DISTANCE_HOST_FORMAT") == nullptr;
+        if (job.gpu_text)
+            for (int g = 0; g < G && job.gpu_text; ++g)
+                for (size_t k = 0; k < loaded.size(); ++k) {
+                    std::string chars;
+                    std::vector<uint64_t> offs(loaded[k].n + 1, 0);
+                    for (size_t r = 0; r < loaded[k].n; ++r) {
+                        chars += loaded[k].ids[r];
+                        offs[r + 1] = chars.size();
+                    }
+                    if (dst_set_ids(gpus[g].h, (int)k, chars.data(), offs.data(), loaded[k].n) != DST_OK)
+                        job.gpu_text = false;   // (e.g. 4 GB of ids): the host formatter takes over
+                }
         run_slabs(gpus, job, 0, 1, a.slab_pairs, wr);
     } else {
         // ---- stream(): src/lib.rs:269-365; stream_fasta(): src/fastaio.rs:215-286 ---------------

@@ -964,7 +964,9 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
-    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, ctx->host_out, ctx->hot_tally})
+    for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, ctx->host_out, ctx->hot_tally, ctx->text_res,
+                    ctx->text_num, (void *)ctx->text_len, (void *)ctx->text_scan, (void *)ctx->text_buf, (void *)ctx->text_flag,
+                    (void *)ctx->ids[0].off, (void *)ctx->ids[0].chars, (void *)ctx->ids[1].off, (void *)ctx->ids[1].chars})
         if (b)
             (void)hipFree(b);
     if (ctx->scratch)

@@ -58,6 +58,20 @@ struct dst_ctx {
     size_t scratch_bytes = 0;
     hipEvent_t scratch_free = nullptr;  // recorded after the last reader of `scratch`
     bool scratch_used = false;
+    // TSV text on the device (dst_text.hip): the sets' record ids and grow-only scratch
+    struct Ids {
+        uint32_t *off = nullptr;  // [n + 1] into chars
+        char *chars = nullptr;
+        size_t off_bytes = 0, chars_bytes = 0;
+        uint64_t n = 0;
+    } ids[2];
+    void *text_res = nullptr;      // the slab's results (8 B per pair)
+    void *text_num = nullptr;      // 32-byte number records
+    uint32_t *text_len = nullptr;  // line lengths -> offsets
+    uint32_t *text_scan = nullptr;
+    char *text_buf = nullptr;
+    uint32_t *text_flag = nullptr;
+    size_t text_res_bytes = 0, text_num_bytes = 0, text_len_bytes = 0, text_scan_bytes = 0, text_buf_bytes = 0;
     hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;

@@ -290,6 +290,30 @@ class Engine:
         self._check(self._lib.dst_run_rect(self._h, m, row_slot, col_slot, row_begin, row_end,
                                            OUT_TALLY if tallies else OUT_DISTANCE, d_out, capacity, stream))
 
+    def set_ids(self, slot: int, ids: list[str]):
+        """Record ids of the packed set in `slot` (dst_set_ids), for the device-side TSV text."""
+        blobs = [s.encode() for s in ids]
+        offs = np.zeros(len(blobs) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(b) for b in blobs])
+        chars = b"".join(blobs)
+        self._check(self._lib.dst_set_ids(self._h, slot, chars, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(blobs)))
+
+    def text_square(self, measure, row_begin: int, row_end: int, capacity: int = 1 << 26) -> bytes:
+        """TSV lines of rows [row_begin, row_end) x later records, formatted on the GPU (dst_text_square)."""
+        buf = C.create_string_buffer(capacity)
+        n = C.c_size_t(0)
+        self._check(self._lib.dst_text_square(self._h, _measure_id(measure), row_begin, row_end, C.addressof(buf), capacity,
+                                              C.byref(n)))
+        return buf.raw[:n.value]
+
+    def text_rect(self, measure, row_slot: int, col_slot: int, row_begin: int, row_end: int, swap_ids: bool = False,
+                  capacity: int = 1 << 26) -> bytes:
+        buf = C.create_string_buffer(capacity)
+        n = C.c_size_t(0)
+        self._check(self._lib.dst_text_rect(self._h, _measure_id(measure), row_slot, col_slot, row_begin, row_end,
+                                            int(swap_ids), C.addressof(buf), capacity, C.byref(n)))
+        return buf.raw[:n.value]
+
     def last_kernel_ms(self) -> dict:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self._check(self._lib.dst_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)))

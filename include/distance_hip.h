@@ -267,6 +267,21 @@ int dst_finalize(int measure, const uint32_t *tallies, const uint32_t *q_counts,
  * (no NUL counted); if that is >= cap the text was truncated to cap-1 characters. */
 int dst_format_distance(int measure, double as_float, int64_t as_int, char *buf, size_t cap);
 
+/* ---- TSV text on the device ---------------------------------------------------------------- */
+/* gather_write()'s output (src/lib.rs:612-644) produced by the GPU: "id1\tid2\tvalue\n" per pair of rows
+ * [row_begin, row_end) in canonical order, `{}` / `{:.12}` exactly as dst_format_distance prints one value.
+ * dst_set_ids gives the record ids of the packed set in `slot` (record r: chars[offsets[r] .. offsets[r+1])); they
+ * stay valid across uploads of the same record count.  The text goes to `out` (host memory; page-locked memory
+ * from dst_host_alloc copies at link speed), *len receives its length.  At most 2^31 pairs, 65,535 rows and 4 GB of
+ * text per call.  DST_ERR_CAPACITY: `capacity` is too small; DST_ERR_STATE: a value has no short text (|v| >= 1.8e7,
+ * which no distance reaches): format those rows on the host.  dst_text_rect: swap_ids != 0 prints the column
+ * record's id first (the value is the one dst_run_rect gives). */
+int dst_set_ids(dst_ctx *ctx, int slot, const char *chars, const uint64_t *offsets, uint64_t n);
+int dst_text_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, char *out, size_t capacity,
+                    size_t *len);
+int dst_text_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin, uint64_t row_end,
+                  int swap_ids, char *out, size_t capacity, size_t *len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,8 +44,13 @@ def write_fasta(path, ids, seqs, width=0):
 
 
 def cli(args, stdin=None):
+    """Every run twice: the TSV lines formatted by the GPU (the default in load mode, dst_text_*) and by the host's
+    formatter pool (DISTANCE_HOST_FORMAT=1) — the two must be the same bytes."""
     r = subprocess.run([CLI] + args, input=stdin, capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
+    h = subprocess.run([CLI] + args, input=stdin, capture_output=True, env=dict(os.environ, DISTANCE_HOST_FORMAT="1"))
+    assert h.returncode == 0, h.stderr.decode()
+    assert r.stdout == h.stdout, "GPU-formatted and host-formatted TSV differ"
     return r.stdout.decode()
 
 

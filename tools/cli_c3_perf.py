@@ -21,11 +21,15 @@ with open(path, "wb") as fh:
         fh.write(synth.fasta_bytes(synth.SEED ^ 3, codes, first=r0))
 print(f"# wrote {path}: {os.path.getsize(path) / 1e9:.2f} GB in {time.time() - t0:.1f} s", flush=True)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "distance_amd", "cli", "distance")
-for args in (["-m", measure, path, "-o", "/dev/null"], ["-m", measure, path, "-o", "/dev/null", "-t", "16"], ["-m", measure, path, "-o", "/dev/null", "-t", "32"]):
+runs = (([], {}, "TSV lines formatted on the GPU (default)"),
+        ([], {"DISTANCE_HOST_FORMAT": "1"}, "host formatter pool, default threads"),
+        (["-t", "32"], {"DISTANCE_HOST_FORMAT": "1"}, "host formatter pool, -t 32"))
+for extra, env, what in runs:
+    args = ["-m", measure, path, "-o", "/dev/null"] + extra
     t0 = time.time()
-    r = subprocess.run([cli] + args, env=dict(os.environ, DISTANCE_TIMING="1"), capture_output=True)
+    r = subprocess.run([cli] + args, env=dict(os.environ, DISTANCE_TIMING="1", **env), capture_output=True)
     dt = time.time() - t0
     pairs = n * (n - 1) // 2
-    print(f"# distance {' '.join(args)}: rc={r.returncode} {dt:.2f} s wall, {pairs / dt:.3e} pairs/s ({pairs} TSV lines)")
+    print(f"# {what}: distance {' '.join(args)}: rc={r.returncode} {dt:.2f} s wall, {pairs / dt:.3e} pairs/s ({pairs} TSV lines)")
     print(r.stderr.decode())
 os.remove(path)

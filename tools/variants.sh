@@ -19,7 +19,7 @@ while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c $SRC.hip -o ../../build/variants/${SRC}_$name.o
   objs=""
-  for o in dst_kernels dst_consensus dst_api dst_stream dst_host dst_gather; do
+  for o in dst_kernels dst_consensus dst_text dst_api dst_stream dst_host dst_gather; do
     if [ $o = $SRC ]; then objs="$objs ../../build/variants/${SRC}_$name.o"; else objs="$objs ../../build/obj/$o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -no-hip-rt $objs \
