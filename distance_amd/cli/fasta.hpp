@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 
 namespace cli {
@@ -108,58 +109,73 @@ private:
     size_t pos_ = 0, len_ = 0;
 };
 
+// A block of whole records: uninitialised storage filled by fread (std::string::resize would zero it first).
+struct Block {
+    std::unique_ptr<char[]> data;
+    size_t len = 0, cap = 0;
+};
+
 // Cuts a stream into blocks of whole records so that blocks can be parsed in parallel: a block ends
-// just before a line that starts with '>' (every such line starts a record for bio's reader).
+// just before a line that starts with '>' (every such line starts a record for bio's reader).  Each block is read
+// straight into its own buffer; only the partial record behind the last cut is copied (to the next block's front).
 class BlockReader {
 public:
     BlockReader(FILE *fh, size_t target_bytes) : fh_(fh), target_(target_bytes ? target_bytes : 1) {}
     // false at end of input; otherwise `out` holds >= 1 whole record (the rest of the input at EOF)
-    bool next(std::string &out)
+    bool next(Block &out)
     {
-        out.clear();
+        Block cur;
+        cur.cap = carry_.len + target_;
+        cur.data.reset(new char[cur.cap]);
+        if (carry_.len)
+            std::memcpy(cur.data.get(), carry_.data.get(), carry_.len);
+        cur.len = carry_.len;
+        carry_ = Block();
         for (;;) {
-            if (!eof_ && carry_.size() < target_) {
-                const size_t old = carry_.size();
-                carry_.resize(old + target_);
-                const size_t got = std::fread(&carry_[old], 1, target_, fh_);
-                carry_.resize(old + got);
+            if (!eof_) {
+                if (cur.len == cur.cap) {   // one record longer than the target: grow and keep reading
+                    Block bigger;
+                    bigger.cap = cur.cap + target_;
+                    bigger.data.reset(new char[bigger.cap]);
+                    std::memcpy(bigger.data.get(), cur.data.get(), cur.len);
+                    bigger.len = cur.len;
+                    cur = std::move(bigger);
+                }
+                const size_t got = std::fread(cur.data.get() + cur.len, 1, cur.cap - cur.len, fh_);
+                cur.len += got;
                 if (got == 0)
                     eof_ = true;
             }
-            if (carry_.empty())
+            if (cur.len == 0)
                 return false;
             if (eof_) {
-                out.swap(carry_);
-                carry_.clear();
+                out = std::move(cur);
                 return true;
             }
             // last "\n>" in the buffer: everything before the '>' is whole records
-            size_t cut = std::string::npos;
-            for (size_t p = carry_.size(); p-- > 1;) {
-                if (carry_[p] == '>' && carry_[p - 1] == '\n') {
+            const char *d = cur.data.get();
+            size_t cut = 0;
+            for (size_t p = cur.len; p-- > 1;) {
+                if (d[p] == '>' && d[p - 1] == '\n') {
                     cut = p;
                     break;
                 }
             }
-            if (cut != std::string::npos && cut > 0) {
-                out.assign(carry_, 0, cut);
-                carry_.erase(0, cut);
+            if (cut > 0) {
+                carry_.len = carry_.cap = cur.len - cut;
+                carry_.data.reset(new char[carry_.cap ? carry_.cap : 1]);
+                std::memcpy(carry_.data.get(), d + cut, carry_.len);
+                cur.len = cut;
+                out = std::move(cur);
                 return true;
             }
-            // one record longer than the target: keep reading
-            const size_t old = carry_.size();
-            carry_.resize(old + target_);
-            const size_t got = std::fread(&carry_[old], 1, target_, fh_);
-            carry_.resize(old + got);
-            if (got == 0)
-                eof_ = true;
         }
     }
 
 private:
     FILE *fh_;
     size_t target_;
-    std::string carry_;
+    Block carry_;
     bool eof_ = false;
 };
 

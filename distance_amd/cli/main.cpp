@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <csignal>
 #include <cstdio>
+#include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -230,9 +231,20 @@ void encoding_array(uint8_t a[256])
     a[(unsigned char)'?'] = 242;
 }
 
+// std::vector that leaves new bytes uninitialised (resize() before a fill would touch every page twice)
+template <class T>
+struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using Bytes = std::vector<uint8_t, NoInit<uint8_t>>;
+
 struct Alignment {
     std::vector<std::string> ids;
-    std::vector<uint8_t> codes;      // n x width, row-major
+    Bytes codes;                     // n x width, row-major
     std::vector<uint32_t> counts;    // n x 4 {A,T,G,C}: only filled for streamed tn93 batches
     size_t n = 0, width = 0;
 };
@@ -265,50 +277,98 @@ struct ParsedBlock {
     bool stop = false;  // an empty record ended bio's Records iterator: nothing after it is read
 };
 
-ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool count_raw_upper, bool fixed_width,
+ParsedBlock parse_block(const cli::Block &block, const uint8_t *table, bool count_raw_upper, bool fixed_width,
                         size_t width, bool width_first)
 {
+    // In place on the block's bytes, with fasta.hpp's tokenisation (FastaReader is the readable statement of it and
+    // the sequential reader the host tests compare this with): a record starts at a line beginning with '>';
+    // id = header up to the first whitespace, the rest (trailing whitespace trimmed) is the description; every
+    // following line up to the next '>' line is sequence, trailing whitespace trimmed.  No per-line copies: the
+    // lines are encoded straight from the block into the codes.
     ParsedBlock out;
     out.al = std::make_unique<Alignment>();
     Alignment &al = *out.al;
     al.width = width;
-    cli::FastaReader reader(block.data(), block.size());
-    cli::FastaRecord rec;
+    al.codes.reserve(block.len);   // an upper bound: a code per sequence byte
+    const char *data = block.data.get();
+    const size_t len = block.len;
+    auto is_space = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
     bool first = !fixed_width;
-    for (;;) {
-        const int rc = reader.next(rec);
-        if (rc < 0) {
-            out.error = reader.error();
+    std::vector<std::pair<const char *, size_t>> parts;
+    std::string id;
+    size_t pos = 0;
+    while (pos < len) {
+        // header line
+        const char *h = data + pos;
+        const char *nl = (const char *)std::memchr(h, '\n', len - pos);
+        size_t hlen = nl ? (size_t)(nl - h) + 1 : len - pos;
+        if (h[0] != '>') {
+            out.error = "Expected > at record start.";
             return out;
         }
-        if (rc == 0)
-            break;
-        if (rec.id.empty() && !rec.has_desc && rec.seq.empty()) {
+        pos += hlen;
+        size_t end = hlen;
+        while (end > 1 && is_space((unsigned char)h[end - 1]))
+            --end;
+        size_t p = 1;
+        while (p < end && !is_space((unsigned char)h[p]))
+            ++p;
+        id.assign(h + 1, p - 1);
+        const bool has_desc = p < end;
+        // sequence lines
+        parts.clear();
+        size_t total = 0;
+        while (pos < len && data[pos] != '>') {
+            const char *l = data + pos;
+            const char *e = (const char *)std::memchr(l, '\n', len - pos);
+            const size_t llen = e ? (size_t)(e - l) + 1 : len - pos;
+            pos += llen;
+            size_t keep = llen;
+            while (keep > 0 && is_space((unsigned char)l[keep - 1]))
+                --keep;
+            if (keep) {
+                parts.emplace_back(l, keep);
+                total += keep;
+            }
+        }
+        if (id.empty() && !has_desc && total == 0) {
             out.stop = true;  // bio's Records iterator stops at an empty record
             break;
         }
         // stream_fasta() compares widths BEFORE encoding (src/fastaio.rs:246-254); load_fasta() encodes first
         // (src/fastaio.rs:182) and compares afterwards (:186-190), so a loaded record that is both the wrong
         // length and holds an invalid character reports the character.
-        if (width_first && rec.seq.size() != al.width) {
-            out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 246-248
+        if (width_first && total != al.width) {
+            out.error = err_lengths(total, al.width);  // src/fastaio.rs:93-95, 246-248
             return out;
         }
         // encode() / encode_count_bases(): src/fastaio.rs:101-145
         const size_t at = al.codes.size();
-        al.codes.resize(at + rec.seq.size());
+        al.codes.resize(at + total);
+        uint8_t *dst = al.codes.data() + at;
         uint32_t counting[256];
         if (count_raw_upper)
             std::memset(counting, 0, sizeof counting);
-        for (size_t i = 0; i < rec.seq.size(); ++i) {
-            const unsigned char c = (unsigned char)rec.seq[i];
-            if (table[c] == 0) {
-                out.error = err_invalid_nuc(rec.id, c);
-                return out;
+        for (const auto &part : parts) {
+            const unsigned char *src = (const unsigned char *)part.first;
+            const size_t n = part.second;
+            uint8_t bad = 0xFF;   // AND of the codes: 0 as soon as one byte has none (every code has bit 7, 6, 5 or 4)
+            for (size_t i = 0; i < n; ++i) {
+                const uint8_t code = table[src[i]];
+                dst[i] = code;
+                bad = code ? bad : 0;
             }
-            al.codes[at + i] = table[c];
+            if (!bad) {
+                for (size_t i = 0; i < n; ++i)
+                    if (table[src[i]] == 0) {
+                        out.error = err_invalid_nuc(id, src[i]);
+                        return out;
+                    }
+            }
             if (count_raw_upper)
-                counting[c] += 1;
+                for (size_t i = 0; i < n; ++i)
+                    counting[src[i]] += 1;
+            dst += n;
         }
         if (count_raw_upper) {
             al.counts.push_back(counting['A']);
@@ -318,14 +378,14 @@ ParsedBlock parse_block(const std::string &block, const uint8_t *table, bool cou
         }
         if (!width_first) {
             if (first) {
-                al.width = rec.seq.size();
+                al.width = total;
                 first = false;
-            } else if (rec.seq.size() != al.width) {
-                out.error = err_lengths(rec.seq.size(), al.width);  // src/fastaio.rs:93-95, 186-190
+            } else if (total != al.width) {
+                out.error = err_lengths(total, al.width);  // src/fastaio.rs:93-95, 186-190
                 return out;
             }
         }
-        al.ids.push_back(rec.id);
+        al.ids.push_back(id);
         al.n += 1;
     }
     return out;
@@ -339,7 +399,7 @@ void parse_stream(FILE *fh, size_t block_bytes, size_t lookahead, const uint8_t 
 {
     cli::BlockReader blocks(fh, block_bytes);
     std::deque<std::future<ParsedBlock>> inflight;
-    std::string block;
+    cli::Block block;
     bool more = true, width_known = fixed_width;
     size_t w = width;
     while (more || !inflight.empty()) {
@@ -350,10 +410,11 @@ void parse_stream(FILE *fh, size_t block_bytes, size_t lookahead, const uint8_t 
                 break;
             }
             inflight.push_back(std::async(std::launch::async,
-                                          [b = std::move(block), table, count_raw_upper, width_known, w, fixed_width]() {
-                                              return parse_block(b, table, count_raw_upper, width_known, w, fixed_width);
+                                          [b = std::make_shared<cli::Block>(std::move(block)), table, count_raw_upper,
+                                           width_known, w, fixed_width]() {
+                                              return parse_block(*b, table, count_raw_upper, width_known, w, fixed_width);
                                           }));
-            block.clear();
+            block = cli::Block();
         }
         if (inflight.empty())
             break;
@@ -383,6 +444,10 @@ Alignment load_fasta(FILE *fh, const uint8_t *table, size_t threads)
     // DISTANCE_PARSE_BLOCK_BYTES: test hook (tiny blocks put the records of a small file into different parse blocks)
     const char *bb = std::getenv("DISTANCE_PARSE_BLOCK_BYTES");
     const size_t block_bytes = bb && std::atol(bb) > 0 ? (size_t)std::atol(bb) : (size_t)32 << 20;
+    // the codes are fewer than the file's bytes: one allocation, no growth copies of a multi-GB vector
+    struct stat st;
+    if (fstat(fileno(fh), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0)
+        al.codes.reserve((size_t)st.st_size);
     parse_stream(fh, block_bytes, threads, table, false, false, 0, [&](std::unique_ptr<Alignment> part) {
         if (part->n == 0)
             return;
@@ -390,7 +455,9 @@ Alignment load_fasta(FILE *fh, const uint8_t *table, size_t threads)
             al.width = part->width;
             first = false;
         }
-        al.codes.insert(al.codes.end(), part->codes.begin(), part->codes.end());
+        const size_t at = al.codes.size();
+        al.codes.resize(at + part->codes.size());
+        std::memcpy(al.codes.data() + at, part->codes.data(), part->codes.size());
         for (auto &id : part->ids)
             al.ids.push_back(std::move(id));
         al.n += part->n;
