@@ -554,7 +554,11 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
 // sum_s p_s^2 intersection events; the hybrid path the dense cost of the H hot sites (p_s > 3.3 %), one round trip of
 // their tallies through HBM, and the events of the cold sites only.  Constants: measured on MI355X, seconds
 // (tools/calibrate.py, profiles/r02/consensus_calibration.txt).
-int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles)
+// share: this launch's part of the pair space of the two sets.  A run over a row range is one slab of a job that goes
+// on to cover the other rows (the CLI's slabs, a rank's sub-slabs): the lists are built once and serve all of them, so
+// a slab is charged its share of the build — every slab then decides like the whole job would (charged in full, each
+// 4 Mi-pair slab of a 50,000-record run chose the dense kernels: 0.9 ms instead of 0.03).
+int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles, double share)
 {
     //                                            n       n_high  raw      jc69     k80      tn93
     static const double dense_site_pairs_per_s[6] = {2.9e14, 2.9e14, 1.95e14, 1.92e14, 1.82e14, 1.48e14};
@@ -569,7 +573,10 @@ int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uin
     const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[measure];
     // building the lists reads four bit-planes twice; walking a row's list costs one bucket lookup per panel
     const bool have_lists = rows.rec.valid && cols.site.valid;
-    const double build = (double)(rows.n + cols.n) * (double)cols.len * 0.5e-12 + 1.5e-4;
+    // (lengths counted and entries slotted by the pack already: one pass over the slots; else two over four planes)
+    const bool from_pack = &rows == &cols && cols.rec.pre_valid && cols.rec.pre_epoch == cols.epoch;
+    const double build = ((double)(rows.n + cols.n) * (double)cols.len * (from_pack ? 0.1e-12 : 0.5e-12) + 1.5e-4) *
+                         std::min(1.0, std::max(share, 1e-3));
     const double walk = (double)ntiles * kConsensusRowsPerTile * 1e-9 / 256.0;
     const double cons = (double)pairs * (out_s_per_pair[measure] + events * event_s) +
                         ((have_lists && !rows.rec.without_hot) ? 0.0 : build) + walk * mean_list + 3e-5;
@@ -660,7 +667,8 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         const uint64_t n_panels = (cols.n + kPanelCols - 1) / kPanelCols;
         const uint64_t tiles_est = std::max<uint64_t>(1, n_panels * ((re - rb + kConsensusRowsPerTile - 1) / kConsensusRowsPerTile) / (square ? 2 : 1));
         path = ctx->path != DST_PATH_AUTO ? ctx->path
-                                          : cheapest_path(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu));
+                                          : cheapest_path(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu),
+                                                          (double)total_pairs / (double)std::max<uint64_t>(pairs_in_rows(square, cols.n, 0, rows.n), 1));
         const uint64_t n_hot = cols.ref.h_stats[4];
         if (path == DST_PATH_HYBRID && (n_hot == 0 || n_hot * 2 > cols.len))
             path = n_hot == 0 ? DST_PATH_CONSENSUS : DST_PATH_DENSE;  // nothing hot / mostly hot: the plain paths
