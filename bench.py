@@ -58,7 +58,7 @@ OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  
 RAW_STEP_CEILING_NS = 10.6
 # consensus path: f64 VALU instructions of the fused finalisation per pair (ISA of consensus_pair_kernel: conversions,
 # the expanded division sequences, dst_log's polynomial), and the f64 vector peak in fma lanes per second
-F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 14, "jc69": 45, "k80": 80, "tn93": 250}
+F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 8, "jc69": 34, "k80": 56, "tn93": 234}   # counted in build/asm/dst_consensus.s
 F64_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
 
 

@@ -67,11 +67,15 @@ __device__ __forceinline__ double rcp_int24(double b)
     return fma(y0, fma(-b, y0, 1.0), y0);
 }
 
+// the IEEE divisions themselves, out of line: inlined beside the fast paths hipcc computes BOTH sides of the test and
+// selects (a division has no side effect), which costs more than the division alone
+__device__ __attribute__((noinline)) double div_plain(double a, double b) { return a / b; }
+
 __device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measures.rs:68
 {
     const double nd = (double)n, dd = (double)d;
     if (d == 0 || (n | d) >> 24)
-        return nd / dd;
+        return div_plain(nd, dd);
     const double y = rcp_int24(dd);
     const double q = nd * y;
     return fma(fma(-dd, q, nd), y, q);
@@ -107,7 +111,7 @@ __device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_
     if (count_L == 0)
         return fin_k80_plain(count_L, ts, tv);
     // ts, tv <= count_L are integers: below 2^24 the quotients need no real division (rcp_int24)
-    const double L = (double)count_L, inv_L = count_L >> 24 ? 1.0 / L : rcp_int24(L);
+    const double L = (double)count_L, inv_L = count_L >> 24 ? div_plain(1.0, L) : rcp_int24(L);
     const double P = div_by((double)ts, L, inv_L);
     const double Q = div_by((double)tv, L, inv_L);
     return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
@@ -152,7 +156,7 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     // the base-frequency and P1 / P2 / Q quotients are integers over integers: below 2^24 they need no real division
     const uint64_t sL = sA + sT + sG + sC;
     const bool small = ((sL | (uint64_t)count_L | (uint64_t)count_d) >> 24) == 0;
-    const double L = (double)sL, inv_L = small ? rcp_int24(L) : 1.0 / L;
+    const double L = (double)sL, inv_L = small ? rcp_int24(L) : div_plain(1.0, L);
     const double g_A = div_by((double)sA, L, inv_L);
     const double g_C = div_by((double)sC, L, inv_L);
     const double g_G = div_by((double)sG, L, inv_L);
@@ -163,7 +167,7 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     const double k1 = div_by(2.0 * g_A * g_G, g_R, inv_R);
     const double k2 = div_by(2.0 * g_T * g_C, g_Y, inv_Y);
     const double k3 = 2.0 * (g_R * g_Y - div_by(g_A * g_G * g_Y, g_R, inv_R) - div_by(g_T * g_C * g_R, g_Y, inv_Y));
-    const double cL = (double)count_L, inv_cL = small ? rcp_int24(cL) : 1.0 / cL;
+    const double cL = (double)count_L, inv_cL = small ? rcp_int24(cL) : div_plain(1.0, cL);
     const double P1 = div_by((double)count_P1, cL, inv_cL);
     const double P2 = div_by((double)count_P2, cL, inv_cL);
     const double Q = div_by((double)(count_d - (count_P1 + count_P2)), cL, inv_cL);
