@@ -824,6 +824,20 @@ constexpr int event_waves()
     return OUT == DST_TN93 || OUT == DST_K80 ? 1 : 2;
 #endif
 }
+// 32-bit words of dynamic LDS before the logarithm table: accumulators, h table, row offsets, (ALIGNED) A(column)
+template <int FAM, bool WIDE, int OUT>
+constexpr size_t cpair_smem_words()
+{
+    constexpr int W = Pack<FAM, WIDE>::W;
+#ifdef DST_DBG_RB
+    constexpr int RBL = DST_DBG_RB;
+#else
+    constexpr int RBL = kAccRows;
+#endif
+    size_t words = (size_t)2 * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
+                   (aligned_output<FAM, WIDE, OUT>() ? kPanelCols : 0);
+    return (words + 3) & ~(size_t)3;   // the table's entries are 16 bytes
+}
 constexpr int kEventWavesHeavy = 4;   // launches with many events per pair or long lists (ConsensusLaunch::heavy_events)
 
 // the value must be in its register HERE (an empty asm the compiler cannot move a definition across)
@@ -915,6 +929,10 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     // comes from an LDS copy of the panel's constants instead of registers.
     constexpr bool ALIGNED = aligned_output<FAM, WIDE, OUT>();
     uint32_t *cola = rofs + kTileRowsMax + 1;              // ALIGNED: [kPanelCols] A(column) of this panel
+    // the logarithm's table (2 KB) in LDS for the measures that take one: an output wave must not load from global
+    // memory between its result stores (one in-order counter for loads and stores: the load waits for every earlier store)
+    constexpr bool LOGS = OUT == DST_JC69 || OUT == DST_K80 || OUT == DST_TN93;
+    LogEntry *logtab = reinterpret_cast<LogEntry *>(smem + cpair_smem_words<FAM, WIDE, OUT>());
 
     const ConsensusTile tile = tiles[blockIdx.x];
     const uint32_t panel0 = tile.panel * kPanelCols;
@@ -932,6 +950,9 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     if constexpr (ALIGNED)
         for (uint32_t k = threadIdx.x; k < kPanelCols; k += blockDim.x)
             cola[k] = k < pcols ? col_a[panel0 + k] : 0u;
+    if constexpr (LOGS)
+        if (threadIdx.x < 128)
+            logtab[threadIdx.x] = kLogTab[threadIdx.x];
     // A(column) of an output thread's column pairs: constant over the rows of the tile, kept in registers —
     // except for tn93, whose finalisation needs the registers more (there the 4 bytes are re-read per pair
     // and the pair loop stays rolled: one copy of the formula in the code)
@@ -1184,7 +1205,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                                 uint4 tc = make_uint4(0, 0, 0, 0);
                                 if constexpr (OUT == DST_TN93)
                                     tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
-                                d[h] = finalize_pair<OUT>(o[h], qc, tc);
+                                d[h] = finalize_pair<OUT>(o[h], qc, tc, LOGS ? logtab : kLogTab);
                             }
                         };
                         fin(0);   // (two copies of the formula: the two results' dependency chains interleave)
@@ -1390,14 +1411,8 @@ namespace {
 template <int FAM, bool WIDE, int OUT, int EW>
 hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
-    constexpr int W = Pack<FAM, WIDE>::W;
-#ifdef DST_DBG_RB
-    constexpr int RBL = DST_DBG_RB;
-#else
-    constexpr int RBL = kAccRows;
-#endif
-    const size_t smem = ((size_t)2 * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
-                         (aligned_output<FAM, WIDE, OUT>() ? kPanelCols : 0)) * sizeof(uint32_t);
+    const size_t smem = cpair_smem_words<FAM, WIDE, OUT>() * sizeof(uint32_t) +
+                        (OUT == DST_JC69 || OUT == DST_K80 || OUT == DST_TN93 ? 128 * sizeof(LogEntry) : 0);
     auto kern = consensus_pair_kernel<FAM, WIDE, OUT, EW>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -27,7 +27,10 @@ __device__ const LogEntry kLogTab[128] = {DST_LOG_TABLE};
 
 __device__ __attribute__((noinline)) double dst_log_special(double x) { return log(x); }
 
-__device__ __forceinline__ double dst_log(double x)
+// `tab`: kLogTab, or a copy of it in LDS — the consensus pair kernel's output waves must not LOAD from global memory
+// between their result stores (gfx950 counts loads and stores in one in-order counter: the load would wait for every
+// store issued before it to land)
+__device__ __forceinline__ double dst_log(double x, const LogEntry *tab = kLogTab)
 {
     if (!(x >= 0x1p-1000 && x < __builtin_huge_val()))
         return dst_log_special(x);  // one out-of-line copy of the library's code per kernel, rarely run
@@ -35,7 +38,7 @@ __device__ __forceinline__ double dst_log(double x)
     const int64_t k = (int64_t)tmp >> 52;
     const uint64_t m = tmp & 0x000FFFFFFFFFFFFFull;
     const double z = __longlong_as_double((long long)(0x3FE6000000000000ull + m));
-    const LogEntry e = kLogTab[(uint32_t)(m >> 45)];
+    const LogEntry e = tab[(uint32_t)(m >> 45)];
     const double r = fma(z, e.invc, -1.0);
     const double kd = (double)k;
     const double w = fma(kd, DST_LN2_HI, e.logc);
@@ -81,10 +84,10 @@ __device__ __forceinline__ double fin_raw(uint32_t n, uint32_t d)  // src/measur
     return fma(fma(-dd, q, nd), y, q);
 }
 
-__device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d)  // src/measures.rs:72-77
+__device__ __forceinline__ double fin_jc69(uint32_t n, uint32_t d, const LogEntry *tab = kLogTab)  // src/measures.rs:72-77
 {
     const double p = fin_raw(n, d);
-    return -0.75 * dst_log(1.0 - (4.0 / 3.0) * p);
+    return -0.75 * dst_log(1.0 - (4.0 / 3.0) * p, tab);
 }
 
 // Several correctly rounded quotients over ONE divisor: y = RN(1/b) by a real division, then per numerator
@@ -106,7 +109,7 @@ __device__ __attribute__((noinline)) double fin_k80_plain(uint32_t count_L, uint
     return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
 }
 
-__device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv)  // :109-112
+__device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_t tv, const LogEntry *tab = kLogTab)  // :109-112
 {
     if (count_L == 0)
         return fin_k80_plain(count_L, ts, tv);
@@ -114,7 +117,7 @@ __device__ __forceinline__ double fin_k80(uint32_t count_L, uint32_t ts, uint32_
     const double L = (double)count_L, inv_L = count_L >> 24 ? div_plain(1.0, L) : rcp_int24(L);
     const double P = div_by((double)ts, L, inv_L);
     const double Q = div_by((double)tv, L, inv_L);
-    return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q));
+    return -0.5 * dst_log((1.0 - 2.0 * P - Q) * sqrt(1.0 - 2.0 * Q), tab);
 }
 
 // counts = {A, T, G, C}; sums keep the reference's operand order (target first), :118-190
@@ -147,7 +150,7 @@ __device__ __attribute__((noinline)) double fin_tn93_plain(uint32_t count_L, uin
 // reciprocal each (div_by), and the two integer divisors take theirs from rcp_int24.  The integer sums are exact in f64 (< 2^53), so adding them as integers first gives
 // the reference's values.
 __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, uint32_t count_P1,
-                                           uint32_t count_P2, uint4 qc, uint4 tc)
+                                           uint32_t count_P2, uint4 qc, uint4 tc, const LogEntry *tab = kLogTab)
 {
     const uint64_t sA = (uint64_t)tc.x + qc.x, sT = (uint64_t)tc.y + qc.y, sG = (uint64_t)tc.z + qc.z,
                    sC = (uint64_t)tc.w + qc.w;
@@ -175,7 +178,7 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     const double w1 = 1.0 - P1 / k1 - 0.5 * div_by(Q, g_R, inv_R);
     const double w2 = 1.0 - P2 / k2 - 0.5 * div_by(Q, g_Y, inv_Y);
     const double w3 = 1.0 - Q / (2.0 * g_R * g_Y);
-    double d = -k1 * dst_log(w1) - k2 * dst_log(w2) - k3 * dst_log(w3);
+    double d = -k1 * dst_log(w1, tab) - k2 * dst_log(w2, tab) - k3 * dst_log(w3, tab);
     if (d == 0.0)
         d = 0.0;
     return d;
@@ -189,16 +192,16 @@ constexpr int OUT_TALLY16 = -5;    // uint16 x NT per pair (alignments shorter t
 // OUT >= 0: the measure id whose f64 distance the epilogue writes
 
 template <int MEASURE>
-__device__ __forceinline__ double finalize_pair(const uint32_t *o, uint4 qc, uint4 tc)
+__device__ __forceinline__ double finalize_pair(const uint32_t *o, uint4 qc, uint4 tc, const LogEntry *tab = kLogTab)
 {
     if constexpr (MEASURE == DST_RAW)
         return fin_raw(o[0], o[1]);
     else if constexpr (MEASURE == DST_JC69)
-        return fin_jc69(o[0], o[1]);
+        return fin_jc69(o[0], o[1], tab);
     else if constexpr (MEASURE == DST_K80)
-        return fin_k80(o[0], o[1], o[2]);
+        return fin_k80(o[0], o[1], o[2], tab);
     else
-        return fin_tn93(o[0], o[1], o[2], o[3], qc, tc);
+        return fin_tn93(o[0], o[1], o[2], o[3], qc, tc, tab);
 }
 
 }  // namespace
