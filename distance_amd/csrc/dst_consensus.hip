@@ -953,23 +953,39 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     if constexpr (LOGS)
         if (threadIdx.x < 128)
             logtab[threadIdx.x] = kLogTab[threadIdx.x];
-    // A(column) of an output thread's column pairs: constant over the rows of the tile, kept in registers —
-    // except for tn93, whose finalisation needs the registers more (there the 4 bytes are re-read per pair
-    // and the pair loop stays rolled: one copy of the formula in the code)
-    constexpr bool HOIST = OUT != DST_TN93 && !ALIGNED;
+    // A(column) of an output thread's column pairs — and, for tn93, the columns' base counts — are constant over the
+    // rows of the tile: kept in registers for the whole tile (the panel-relative mapping).  Loading them inside the
+    // output loop would put a global load between the result stores, and gfx950 makes that load wait for every store
+    // issued before it (tn93 with the counts re-read per pair: 15.6 ms; with the load removed for a measurement 14.3).
+    constexpr bool HOIST = !ALIGNED;
+    constexpr bool HOIST_TC = HOIST && OUT == DST_TN93;
+    constexpr int TCW = WIDE ? 4 : 2;   // below 65,536 sites a count fits 16 bits: two words per column
     uint32_t ca[HOIST ? PAIRS : 1][2][W];
+    uint32_t tcp[HOIST_TC ? PAIRS : 1][2][TCW];
     if constexpr (HOIST) {
 #pragma unroll
         for (int j = 0; j < PAIRS; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t k = 2 * tid + 2 * OT * j + h;
+                const bool in = !event_role && k < pcols;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    ca[j][h][w] = (!event_role && k < pcols) ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
-                    // keep the VALUE in a register: left to itself hipcc re-loads it inside the output loop, and on
-                    // gfx950 waiting for that load (vmcnt) also waits for every result store issued before it
+                    ca[j][h][w] = in ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+                    // keep the VALUE in a register: left to itself hipcc re-loads it inside the output loop
                     asm volatile("" : "+v"(ca[j][h][w]));
+                }
+                if constexpr (HOIST_TC) {
+                    const uint4 t4 = in ? reinterpret_cast<const uint4 *>(t_counts)[panel0 + k] : make_uint4(0, 0, 0, 0);
+                    if constexpr (WIDE) {
+                        tcp[j][h][0] = t4.x, tcp[j][h][1] = t4.y, tcp[j][h][2] = t4.z, tcp[j][h][3] = t4.w;
+                    } else {
+                        tcp[j][h][0] = t4.x | t4.y << 16;
+                        tcp[j][h][1] = t4.z | t4.w << 16;
+                    }
+#pragma unroll
+                    for (int x = 0; x < TCW; ++x)
+                        asm volatile("" : "+v"(tcp[j][h][x]));
                 }
             }
     }
@@ -1135,7 +1151,8 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 uint32_t *racc = acc + (b & 1u) * ACC + rb * W * kPanelCols;
                 // two adjacent results of row q: columns panel0 + ks and panel0 + ks + 1 (ks may be -1 .. pcols - 1:
                 // ALIGNED pairs straddle the panel's edges); j: the thread's register copy of A(column) (HOIST)
-                auto do_pair = [&](int32_t ks, int j) {
+                // cav / tcv: the hoisted A(column) words and packed base counts of the two columns (nullptr when ALIGNED)
+                auto do_pair = [&](int32_t ks, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
                     bool in[2], live[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1158,10 +1175,8 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                             uint32_t cav;
                             if constexpr (ALIGNED)
                                 cav = cola[k];
-                            else if constexpr (HOIST)
-                                cav = ca[j][h][w];
                             else
-                                cav = in[h] ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+                                cav = cav2[h][w];
                             tot[w] = a + cav + aq[w];
                         }
                         if (hot && live[h])
@@ -1203,8 +1218,14 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                         auto fin = [&](int h) {
                             if (live[h]) {
                                 uint4 tc = make_uint4(0, 0, 0, 0);
-                                if constexpr (OUT == DST_TN93)
+                                if constexpr (HOIST_TC) {
+                                    if constexpr (WIDE)
+                                        tc = make_uint4(tcv[h][0], tcv[h][1], tcv[h][2], tcv[h][3]);
+                                    else
+                                        tc = make_uint4(tcv[h][0] & 0xFFFFu, tcv[h][0] >> 16, tcv[h][1] & 0xFFFFu, tcv[h][1] >> 16);
+                                } else if constexpr (OUT == DST_TN93) {
                                     tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
+                                }
                                 d[h] = finalize_pair<OUT>(o[h], qc, tc, LOGS ? logtab : kLogTab);
                             }
                         };
@@ -1236,17 +1257,38 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     const uint32_t g0 = idx * BASE + min(idx, REM);
 #pragma unroll
                     for (uint32_t g = 0; g < BASE; ++g)
-                        do_pair((int32_t)(128u * (g0 + g) + 2u * lane) - (int32_t)sh, 0);
+                        do_pair((int32_t)(128u * (g0 + g) + 2u * lane) - (int32_t)sh, nullptr, nullptr);
                     if (idx < REM)
-                        do_pair((int32_t)(128u * (g0 + BASE) + 2u * lane) - (int32_t)sh, 0);
-                } else if constexpr (HOIST) {
+                        do_pair((int32_t)(128u * (g0 + BASE) + 2u * lane) - (int32_t)sh, nullptr, nullptr);
+                } else if constexpr (OUT == DST_TN93) {
+                    // one copy of the pair's code (two of the formula), not PAIRS: tn93's registers are at the limit the
+                    // LDS leaves (128); the hoisted values of slot j are picked by selects, not by indexing
+#pragma unroll 1
+                    for (int j = 0; j < PAIRS; ++j) {
+                        uint32_t cc[2][W], tt[2][TCW];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {
+                                cc[h][w] = ca[0][h][w];
+#pragma unroll
+                                for (int jj = 1; jj < PAIRS; ++jj)
+                                    cc[h][w] = j == jj ? ca[jj][h][w] : cc[h][w];
+                            }
+#pragma unroll
+                            for (int x = 0; x < TCW; ++x) {
+                                tt[h][x] = tcp[0][h][x];
+#pragma unroll
+                                for (int jj = 1; jj < PAIRS; ++jj)
+                                    tt[h][x] = j == jj ? tcp[jj][h][x] : tt[h][x];
+                            }
+                        }
+                        do_pair((int32_t)(2 * tid + 2 * OT * j), cc, tt);
+                    }
+                } else {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair((int32_t)(2 * tid + 2 * OT * j), j);
-                } else {
-#pragma unroll 1
-                    for (int j = 0; j < PAIRS; ++j)
-                        do_pair((int32_t)(2 * tid + 2 * OT * j), j);
+                        do_pair((int32_t)(2 * tid + 2 * OT * j), ca[j], tcp[0]);
                 }
             }
         }
