@@ -810,7 +810,9 @@ void run_slabs(std::vector<Ctx> &gpus, const Job &job, int row_slot, int col_slo
     size_t next_to_write = 0;
     std::atomic<size_t> next_slab{0};
     const size_t n_formatters = 2;
-    const size_t window = gpus.size() * 2 + n_formatters + 1;  // bound on slabs in flight (memory)
+    // bound on slabs in flight (page-locked memory; pinning a 240 MB text buffer costs ~40 ms): with the GPU writing
+    // the text a slab is either being copied back or being written out
+    const size_t window = job.gpu_text ? gpus.size() * 2 + 1 : gpus.size() * 2 + n_formatters + 1;
     PinnedPool pool;
     std::deque<std::pair<size_t, std::unique_ptr<Slab>>> computed;  // GPU done, waiting for a formatter
     size_t gpu_threads_left = gpus.size();
