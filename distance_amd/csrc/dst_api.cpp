@@ -200,7 +200,7 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     // the consensus path's preparation rides on the pack when a run of this set is likely to take it: not forced
     // dense, a shape the lists can index, and more work than the dense kernels finish before lists are built
     const bool want_lists = ctx->path != DST_PATH_DENSE && n >= 2 && len > 0 && n < kEntryMask && len < kSiteMask &&
-                            0.5 * (double)n * (double)n * (double)len >= 2.0e10;
+                            0.5 * (double)n * (double)n * (double)len >= ctx->prep_min_work;
     int rc = pack_queue(ctx, s, d_codes, n, len, row_stride, d_counts, ctx->d_first_bad, stream, want_lists);
     if (rc)
         return rc;
@@ -657,7 +657,7 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
     int rc = DST_OK;
     int path = DST_PATH_DENSE;
     // a launch the dense kernels finish in less time than the lists take to set up goes dense unasked
-    const bool tiny = ctx->path == DST_PATH_AUTO && (double)total_pairs * (double)cols.len < 2.0e10 && !cols.ref.valid;
+    const bool tiny = ctx->path == DST_PATH_AUTO && (double)total_pairs * (double)cols.len < ctx->prep_min_work && !cols.ref.valid;
     if (ctx->path != DST_PATH_DENSE && !tiny && consensus_shape_ok(rows, cols)) {
         rc = ensure_lut(ctx);
         if (!rc)
@@ -1006,6 +1006,16 @@ int dst_set_ksplit(dst_ctx *ctx, int ksplit)
     if (!ctx || ksplit < 0)
         return DST_ERR_ARG;
     ctx->ksplit = ksplit;
+    return DST_OK;
+}
+
+int dst_set_prep_threshold(dst_ctx *ctx, double site_comparisons)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    if (!(site_comparisons >= 0.0))
+        return fail(ctx, DST_ERR_ARG, "threshold must be >= 0");
+    ctx->prep_min_work = site_comparisons;
     return DST_OK;
 }
 

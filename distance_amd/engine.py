@@ -290,6 +290,10 @@ class Engine:
         self._check(self._lib.dst_run_rect(self._h, m, row_slot, col_slot, row_begin, row_end,
                                            OUT_TALLY if tallies else OUT_DISTANCE, d_out, capacity, stream))
 
+    def set_prep_threshold(self, site_comparisons: float):
+        """dst_set_prep_threshold: 0 sends every upload through the consensus path's fused preparation."""
+        self._check(self._lib.dst_set_prep_threshold(self._h, float(site_comparisons)))
+
     def set_ids(self, slot: int, ids: list[str]):
         """Record ids of the packed set in `slot` (dst_set_ids), for the device-side TSV text."""
         blobs = [s.encode() for s in ids]

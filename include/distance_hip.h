@@ -91,6 +91,11 @@ int dst_variant_count(int measure);
  * (exact).  0 = automatic (default: launches with fewer than 1,024 tiles), 1 = never split, k > 1 = force. */
 int dst_set_ksplit(dst_ctx *ctx, int ksplit);
 
+/* DST_PATH_AUTO leaves small jobs to the dense kernels without sampling them: an upload with fewer than
+ * `site_comparisons` (n^2/2 x len) ahead of it skips the consensus path's preparation, and a run below it (with no
+ * reference sequence yet) goes dense.  Default 2e10 (what the dense kernels finish in ~0.1 ms); 0 makes every upload
+ * prepare the lists (tests drive the small shapes of the parity suite through the fused preparation this way). */
+int dst_set_prep_threshold(dst_ctx *ctx, double site_comparisons);
 /* Which kernels a run uses.  Both give the same integers (tallies bit-exact, the same finalisation):
  *  DST_PATH_DENSE:     bit-plane tile kernels, work ~ pairs x L whatever the data (src/measures.rs:14-23,
  *                      56-66, 85-107, 156-175 evaluated at every site).

@@ -14,9 +14,19 @@ pytestmark = pytest.mark.gpu
 MEASURES = ("n", "n_high", "raw", "jc69", "k80", "tn93")
 
 
-def _alignment(rng, n, L):
-    kind = rng.integers(0, 4)
+def _alignment(rng, n, L, fused=False):
+    kind = rng.integers(0, 7 if fused else 4)
     seed = int(rng.integers(0, 2**31))
+    if kind >= 4:
+        # low diversity around the gate of the fused preparation (8 % of the sites deviating): lists counted and slotted
+        # by the pack, chunks with more than 7 differences (back to the planes), lean sets, a few hot columns
+        a = random_alignment(n, L, seed, p_ambig=float(rng.choice([0.0, 0.002])), p_gap=float(rng.choice([0.0, 0.01])),
+                             divergence=float(rng.choice([0.002, 0.02, 0.05, 0.07])))
+        if L > 40 and n > 8 and kind == 6:
+            cols = rng.choice(L, size=max(1, L // 60), replace=False)     # clade-like columns: hot sites
+            rows = rng.random(n) < 0.4
+            a[np.ix_(rows, cols)] = CODES[int(rng.integers(0, 4))]
+        return a
     if kind == 0:
         return uniform_codes(n, L, seed)
     if kind == 1:
@@ -37,21 +47,27 @@ def _close(got, want):
     return abs(got - want) <= 1e-12 and abs(got - want) <= 1e-12 * max(abs(want), 1e-300) + 1e-300 or abs(got - want) <= 1e-12
 
 
-def test_randomised_parity_sweep():
-    rng = np.random.default_rng(20261004)
+@pytest.mark.parametrize("fused", [False, True])
+def test_randomised_parity_sweep(fused):
+    """fused: every upload goes through the consensus path's fused preparation (dst_set_prep_threshold(0)) — the
+    reference sampled from the bytes, list lengths and slots from the pack, lean sets — which the default threshold
+    only gives to jobs of 2e10 site comparisons and more."""
+    rng = np.random.default_rng(20261004 + (77 if fused else 0))
     eng = da.Engine(0)
+    if fused:
+        eng.set_prep_threshold(0.0)
     lib = da.load()
     cases = 0
     try:
         for _ in range(60):
             n = int(rng.choice([1, 2, 3, 17, 64, 65, 200, 513, 700]))
             L = int(rng.choice([0, 1, 31, 32, 33, 127, 128, 129, 500, 2049, 4100]))
-            a = _alignment(rng, n, L)
+            a = _alignment(rng, n, L, fused)
             eng.upload(0, a)
             two = bool(rng.integers(0, 2))
             if two:
                 nb = int(rng.choice([1, 5, 130]))
-                b = _alignment(rng, nb, L)
+                b = _alignment(rng, nb, L, fused)
                 eng.upload(1, b)
             ca = oracle.count_bases_matrix(a)
             for m in rng.choice(MEASURES, size=3, replace=False):

@@ -16,12 +16,16 @@ TOL = 1e-12
 ALL = ("n", "n_high", "raw", "jc69", "k80", "tn93")
 
 
-@pytest.fixture(scope="module", params=["dense", "consensus", "hybrid"])
+@pytest.fixture(scope="module", params=["dense", "consensus", "hybrid", "fused"])
 def eng(request):
     """Every parity test runs on every kernel path: the dense bit-plane tiles, the consensus-delta lists, and the
-    hybrid of the two (hot columns dense, the rest by lists; it falls back to a plain path where there is nothing to split)."""
+    hybrid of the two (hot columns dense, the rest by lists; it falls back to a plain path where there is nothing to split).
+    "fused": the consensus path with its preparation riding on the upload (reference from the bytes, list lengths and
+    slots from the pack, lean sets), which the default threshold keeps for jobs of 2e10 site comparisons and more."""
     e = da.Engine(0)
-    e.set_path(request.param)
+    e.set_path("consensus" if request.param == "fused" else request.param)
+    if request.param == "fused":
+        e.set_prep_threshold(0.0)
     e.path_name = request.param
     yield e
     e.close()
