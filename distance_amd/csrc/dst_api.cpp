@@ -350,7 +350,8 @@ int ensure_lut(dst_ctx *ctx)
     build_consensus_lut(*lut);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_lut, sizeof(ConsensusLut)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lut, lut.get(), sizeof(ConsensusLut), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_total, 2 * sizeof(unsigned long long)));  // [0] list entries, [1] overflow entries
+    if (!ctx->d_total)   // (the text path may have made it already)
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_total, 2 * sizeof(unsigned long long)));  // [0] list entries, [1] overflow entries
     return DST_OK;
 }
 
