@@ -1255,11 +1255,57 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     constexpr uint32_t GROUPS = kPanelCols / 128 + 1, BASE = GROUPS / NOW, REM = GROUPS % NOW;
                     const uint32_t wv = tid >> 6, idx = (wv + NOW - q % NOW) % NOW;
                     const uint32_t g0 = idx * BASE + min(idx, REM);
+                    // A group whose 128 columns all lie inside the panel and past the diagonal (nearly every group) needs
+                    // none of do_pair's per-lane tests: those cost ~50 scalar instructions per pair of results (exec-mask
+                    // bookkeeping), which the one scalar unit of a CU could not keep up with at the write rate.
+                    auto do_group = [&](uint32_t g) {
+                        const int32_t k0 = (int32_t)(128u * g) - (int32_t)sh;          // the group's first column (uniform)
+                        const bool whole = k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) &&
+                                           hot == nullptr;
+                        if (!whole) {
+                            do_pair(k0 + (int32_t)(2u * lane), nullptr, nullptr);
+                            return;
+                        }
+                        const uint32_t k = (uint32_t)k0 + 2u * lane;
+                        const uint32_t a0 = racc[k], a1 = racc[k + 1];
+                        racc[k] = 0;                                                      // (unconditional: cheaper than testing)
+                        racc[k + 1] = 0;
+                        const uint32_t t0 = a0 + cola[k] + aq[0], t1 = a1 + cola[k + 1] + aq[0];
+                        uint32_t o0[NT], o1[NT];
+                        P::unpack(&t0, o0);
+                        P::unpack(&t1, o1);
+                        const uint64_t at = row_at + panel0 + k;
+                        if constexpr (OUT == OUT_INT) {
+                            store_result2(static_cast<int64_t *>(out_v) + at, (int64_t)o0[0], (int64_t)o1[0]);
+                        } else if constexpr (OUT == OUT_TALLY) {
+                            uint32_t *out = static_cast<uint32_t *>(out_v) + at * NT;
+#pragma unroll
+                            for (int x = 0; x < NT; ++x) {
+                                store_result(out + x, o0[x]);
+                                store_result(out + NT + x, o1[x]);
+                            }
+                        } else if constexpr (OUT == OUT_TALLY16) {
+                            uint16_t *out = static_cast<uint16_t *>(out_v) + at * NT;
+#pragma unroll
+                            for (int x = 0; x < NT; ++x) {
+                                store_result(out + x, (uint16_t)o0[x]);
+                                store_result(out + NT + x, (uint16_t)o1[x]);
+                            }
+                        } else {
+                            const uint4 none = make_uint4(0, 0, 0, 0);
+                            const double d0 = finalize_pair<OUT>(o0, none, none), d1 = finalize_pair<OUT>(o1, none, none);
+#ifdef DST_DBG_NO_STORE
+                            if (d0 != -12345.5)
+                                return;
+#endif
+                            store_result2(static_cast<double *>(out_v) + at, d0, d1);
+                        }
+                    };
 #pragma unroll
                     for (uint32_t g = 0; g < BASE; ++g)
-                        do_pair((int32_t)(128u * (g0 + g) + 2u * lane) - (int32_t)sh, nullptr, nullptr);
+                        do_group(g0 + g);
                     if (idx < REM)
-                        do_pair((int32_t)(128u * (g0 + BASE) + 2u * lane) - (int32_t)sh, nullptr, nullptr);
+                        do_group(g0 + BASE);
                 } else if constexpr (OUT == DST_TN93) {
                     // one copy of the pair's code (two of the formula), not PAIRS: tn93's registers are at the limit the
                     // LDS leaves (128); the hoisted values of slot j are picked by selects, not by indexing
