@@ -1244,6 +1244,53 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                         }
                     }
                 };
+                // Two adjacent results whose columns k, k + 1 are known to lie inside the panel and past the diagonal (a
+                // whole group of a wave does): none of do_pair's per-lane tests, which cost ~50 scalar instructions per
+                // pair of results (exec-mask bookkeeping) — more than the one scalar unit of a CU keeps up with at the
+                // write rate.  c0 / c1: A(column) words; t0 / t1: the columns' base counts (tn93).
+                auto fast_pair = [&](uint32_t k, const uint32_t *c0, const uint32_t *c1, uint4 tc0, uint4 tc1) {
+                    uint32_t w0[W], w1[W];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        w0[w] = racc[w * kPanelCols + k] + c0[w] + aq[w];
+                        w1[w] = racc[w * kPanelCols + k + 1] + c1[w] + aq[w];
+                        racc[w * kPanelCols + k] = 0;          // (unconditional: cheaper than testing)
+                        racc[w * kPanelCols + k + 1] = 0;
+                    }
+                    uint32_t o0[NT], o1[NT];
+                    P::unpack(w0, o0);
+                    P::unpack(w1, o1);
+                    const uint64_t at = row_at + panel0 + k;
+                    if constexpr (OUT == OUT_INT) {
+                        store_result2(static_cast<int64_t *>(out_v) + at, (int64_t)o0[0], (int64_t)o1[0]);
+                    } else if constexpr (OUT == OUT_TALLY) {
+                        uint32_t *out = static_cast<uint32_t *>(out_v) + at * NT;
+#pragma unroll
+                        for (int x = 0; x < NT; ++x) {
+                            store_result(out + x, o0[x]);
+                            store_result(out + NT + x, o1[x]);
+                        }
+                    } else if constexpr (OUT == OUT_TALLY16) {
+                        uint16_t *out = static_cast<uint16_t *>(out_v) + at * NT;
+#pragma unroll
+                        for (int x = 0; x < NT; ++x) {
+                            store_result(out + x, (uint16_t)o0[x]);
+                            store_result(out + NT + x, (uint16_t)o1[x]);
+                        }
+                    } else {
+                        const double d0 = finalize_pair<OUT>(o0, qc, tc0, LOGS ? logtab : kLogTab);
+                        const double d1 = finalize_pair<OUT>(o1, qc, tc1, LOGS ? logtab : kLogTab);
+#ifdef DST_DBG_NO_STORE
+                        if (d0 != -12345.5)
+                            return;
+#endif
+                        store_result2(static_cast<double *>(out_v) + at, d0, d1);
+                    }
+                };
+                // is the wave's group of 128 columns from k0 on (uniform) wholly inside the panel and past the diagonal?
+                auto whole_group = [&](int32_t k0) {
+                    return k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) && hot == nullptr;
+                };
                 if constexpr (ALIGNED) {
                     // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
                     // or 17 lines-of-1-KB groups from that line's start go to the output waves as contiguous runs:
@@ -1255,57 +1302,42 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     constexpr uint32_t GROUPS = kPanelCols / 128 + 1, BASE = GROUPS / NOW, REM = GROUPS % NOW;
                     const uint32_t wv = tid >> 6, idx = (wv + NOW - q % NOW) % NOW;
                     const uint32_t g0 = idx * BASE + min(idx, REM);
-                    // A group whose 128 columns all lie inside the panel and past the diagonal (nearly every group) needs
-                    // none of do_pair's per-lane tests: those cost ~50 scalar instructions per pair of results (exec-mask
-                    // bookkeeping), which the one scalar unit of a CU could not keep up with at the write rate.
                     auto do_group = [&](uint32_t g) {
                         const int32_t k0 = (int32_t)(128u * g) - (int32_t)sh;          // the group's first column (uniform)
-                        const bool whole = k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) &&
-                                           hot == nullptr;
-                        if (!whole) {
+                        if (!whole_group(k0)) {
                             do_pair(k0 + (int32_t)(2u * lane), nullptr, nullptr);
                             return;
                         }
                         const uint32_t k = (uint32_t)k0 + 2u * lane;
-                        const uint32_t a0 = racc[k], a1 = racc[k + 1];
-                        racc[k] = 0;                                                      // (unconditional: cheaper than testing)
-                        racc[k + 1] = 0;
-                        const uint32_t t0 = a0 + cola[k] + aq[0], t1 = a1 + cola[k + 1] + aq[0];
-                        uint32_t o0[NT], o1[NT];
-                        P::unpack(&t0, o0);
-                        P::unpack(&t1, o1);
-                        const uint64_t at = row_at + panel0 + k;
-                        if constexpr (OUT == OUT_INT) {
-                            store_result2(static_cast<int64_t *>(out_v) + at, (int64_t)o0[0], (int64_t)o1[0]);
-                        } else if constexpr (OUT == OUT_TALLY) {
-                            uint32_t *out = static_cast<uint32_t *>(out_v) + at * NT;
-#pragma unroll
-                            for (int x = 0; x < NT; ++x) {
-                                store_result(out + x, o0[x]);
-                                store_result(out + NT + x, o1[x]);
-                            }
-                        } else if constexpr (OUT == OUT_TALLY16) {
-                            uint16_t *out = static_cast<uint16_t *>(out_v) + at * NT;
-#pragma unroll
-                            for (int x = 0; x < NT; ++x) {
-                                store_result(out + x, (uint16_t)o0[x]);
-                                store_result(out + NT + x, (uint16_t)o1[x]);
-                            }
-                        } else {
-                            const uint4 none = make_uint4(0, 0, 0, 0);
-                            const double d0 = finalize_pair<OUT>(o0, none, none), d1 = finalize_pair<OUT>(o1, none, none);
-#ifdef DST_DBG_NO_STORE
-                            if (d0 != -12345.5)
-                                return;
-#endif
-                            store_result2(static_cast<double *>(out_v) + at, d0, d1);
-                        }
+                        const uint4 none = make_uint4(0, 0, 0, 0);
+                        fast_pair(k, &cola[k], &cola[k + 1], none, none);
                     };
 #pragma unroll
                     for (uint32_t g = 0; g < BASE; ++g)
                         do_group(g0 + g);
                     if (idx < REM)
                         do_group(g0 + BASE);
+                }
+                // panel-relative mapping: slot j of this wave = columns 2 (tid's wave x 64) + 2 OT j .. + 128
+                auto do_slot = [&](int j, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
+                    const int32_t k0 = (int32_t)(2u * (tid & ~63u) + 2u * OT * (uint32_t)j);
+                    if (!whole_group(k0)) {
+                        do_pair(k0 + (int32_t)(2u * lane), cav2, tcv);
+                        return;
+                    }
+                    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+                    if constexpr (HOIST_TC) {
+                        if constexpr (WIDE) {
+                            t0 = make_uint4(tcv[0][0], tcv[0][1], tcv[0][2], tcv[0][3]);
+                            t1 = make_uint4(tcv[1][0], tcv[1][1], tcv[1][2], tcv[1][3]);
+                        } else {
+                            t0 = make_uint4(tcv[0][0] & 0xFFFFu, tcv[0][0] >> 16, tcv[0][1] & 0xFFFFu, tcv[0][1] >> 16);
+                            t1 = make_uint4(tcv[1][0] & 0xFFFFu, tcv[1][0] >> 16, tcv[1][1] & 0xFFFFu, tcv[1][1] >> 16);
+                        }
+                    }
+                    fast_pair((uint32_t)k0 + 2u * lane, cav2[0], cav2[1], t0, t1);
+                };
+                if constexpr (ALIGNED) {
                 } else if constexpr (OUT == DST_TN93) {
                     // one copy of the pair's code (two of the formula), not PAIRS: tn93's registers are at the limit the
                     // LDS leaves (128); the hoisted values of slot j are picked by selects, not by indexing
@@ -1329,12 +1361,12 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                                     tt[h][x] = j == jj ? tcp[jj][h][x] : tt[h][x];
                             }
                         }
-                        do_pair((int32_t)(2 * tid + 2 * OT * j), cc, tt);
+                        do_slot(j, cc, tt);
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j)
-                        do_pair((int32_t)(2 * tid + 2 * OT * j), ca[j], tcp[0]);
+                        do_slot(j, ca[j], tcp[0]);
                 }
             }
         }
