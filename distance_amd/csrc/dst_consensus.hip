@@ -1069,7 +1069,9 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 if (lane >= (uint32_t)o) incl += up;
             }
             const uint32_t total = __shfl(incl, 63), start = incl - ex;
-            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+            // entry i of the wave's overflow entries: whose bucket (search by shuffles), then its load; the loads of
+            // the NEXT 64 are issued before this 64 are applied (event-heavy launches spend their time here)
+            auto fetch = [&](uint32_t i0, uint32_t &c, uint32_t &meta) {
                 const uint32_t i = i0 + lane;
                 uint32_t lo = 0;
 #pragma unroll
@@ -1077,11 +1079,18 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     const uint32_t v = __shfl(start, (int)(lo + st));
                     if (v <= i) lo += st;   // the last lane whose range starts at or before i (sizes may be 0)
                 }
-                const uint32_t s_o0 = __shfl(o0, (int)lo), s_meta = __shfl(t.meta, (int)lo), s_start = __shfl(start, (int)lo);
-                if (i < total) {
-                    const uint32_t c = site_ent[s_o0 + (i - s_start)];
-                    apply(c & (kPanelCols - 1u), c >> kEntryShift, s_meta);
-                }
+                const uint32_t s_o0 = __shfl(o0, (int)lo), s_start = __shfl(start, (int)lo);
+                meta = __shfl(t.meta, (int)lo);
+                c = i < total ? site_ent[s_o0 + (i - s_start)] : 0u;
+            };
+            uint32_t c_nx = 0, m_nx = 0;
+            fetch(0, c_nx, m_nx);
+            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                const uint32_t c = c_nx, meta = m_nx;
+                if (i0 + 64 < total)
+                    fetch(i0 + 64, c_nx, m_nx);
+                if (i0 + lane < total)
+                    apply(c & (kPanelCols - 1u), c >> kEntryShift, meta);
             }
         }
     };
