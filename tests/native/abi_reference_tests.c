@@ -122,6 +122,23 @@ int main(void)
     CHECK(r2[0] == 0 && r2[1] == 1);
     char text[64];
     CHECK(dst_format_distance(DST_N_HIGH, 0.0, r2[1], text, sizeof text) == 1 && text[0] == '1');
+    /* the same TSV lines written by the GPU (gather_write, lib.rs:612-644): "seq1\tseq2\t1\n" (one file) and
+     * "seq1\tseqA\t0\nseq2\tseqA\t1\n" (two files), as test_integration_1 / _3 expect them (lib.rs:906-1154) */
+    {
+        const char ids1[] = "seq1seq2", ids2[] = "seqA";
+        const uint64_t off1[3] = {0, 4, 8}, off2[2] = {0, 4};
+        char tsv[128];
+        size_t len = 0;
+        OK(dst_set_ids(ctx, 0, ids1, off1, 2));
+        OK(dst_set_ids(ctx, 1, ids2, off2, 1));
+        OK(dst_text_square(ctx, DST_N, 0, 2, tsv, sizeof tsv, &len));
+        CHECK(len == 12 && memcmp(tsv, "seq1\tseq2\t1\n", 12) == 0);
+        OK(dst_text_rect(ctx, DST_N_HIGH, 0, 1, 0, 2, 0, tsv, sizeof tsv, &len));
+        CHECK(len == 24 && memcmp(tsv, "seq1\tseqA\t0\nseq2\tseqA\t1\n", 24) == 0);
+        OK(dst_text_square(ctx, DST_RAW, 0, 2, tsv, sizeof tsv, &len));   /* 1 difference / 6 sites, {:.12} */
+        CHECK(len == 25 && memcmp(tsv, "seq1\tseq2\t0.166666666667\n", 25) == 0);
+        CHECK(dst_text_square(ctx, DST_RAW, 0, 2, tsv, 10, &len) == DST_ERR_CAPACITY);
+    }
 
     /* error behaviour: invalid code byte, capacity, bad measure */
     uint8_t bad[2][6];
