@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_hot, s.rec.pre_totals, s.rec.pre_slots,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_slots,
                     s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -137,23 +137,26 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
     if (want_lists) {
         rc = alloc_ref(ctx, s);
         if (!rc && s.rec.pre_cap < n + 1) {
-            for (void *b : {(void *)s.rec.pre_cold, (void *)s.rec.pre_hot, (void *)s.rec.pre_totals})
-                if (b)
-                    HIP_TRY(ctx, hipFree(b));
+            // one block: [n + 1] cold counts, [n + 1] hot counts, the two totals — one allocation, one memset per upload
+            if (s.rec.pre_cold)
+                HIP_TRY(ctx, hipFree(s.rec.pre_cold));
             s.rec.pre_cold = s.rec.pre_hot = nullptr;
             s.rec.pre_totals = nullptr;
             s.rec.pre_cap = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, (n + 1) * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_hot, (n + 1) * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_totals, 2 * sizeof(unsigned long long)));
+            const size_t words = 2 * (n + 1) + 4 + ((2 * (n + 1)) & 1);   // totals on an 8-byte boundary
+            HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, words * sizeof(uint32_t)));
             s.rec.pre_cap = n + 1;
         }
         if (!rc)
             rc = ensure_bytes(ctx, (void **)&s.rec.pre_slots, &s.rec.pre_slots_cap, s.nchunks * s.npad * sizeof(uint4));
         if (rc)
             return rc;
-        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (n + 1) * sizeof(uint32_t), stream));
-        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_hot, 0, (n + 1) * sizeof(uint32_t), stream));
+        {
+            const size_t cap = s.rec.pre_cap, pad = (2 * cap) & 1;
+            s.rec.pre_hot = s.rec.pre_cold + cap;
+            s.rec.pre_totals = reinterpret_cast<unsigned long long *>(s.rec.pre_cold + 2 * cap + pad);
+            HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (2 * cap + pad + 4) * sizeof(uint32_t), stream));
+        }
         HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream));
         HIP_TRY(ctx, launch_hot_list(s, stream));
         pl.ref_planes = s.ref.planes;
@@ -169,10 +172,8 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
     HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, want_lists ? &pl : nullptr, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
     ctx->timed_pack = true;
-    if (want_lists) {
-        HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_totals, 0, 2 * sizeof(unsigned long long), stream));
+    if (want_lists)
         HIP_TRY(ctx, launch_sum2_u32(s.rec.pre_cold, s.rec.pre_hot, n, s.rec.pre_totals, stream));
-    }
     if (d_counts) {
         HIP_TRY(ctx, hipMemsetAsync(s.counts, 0, s.npad * 4 * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemcpyAsync(s.counts, d_counts, n * 4 * sizeof(uint32_t),

@@ -432,12 +432,15 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
     uint32_t run = 0;
     const uint32_t base0 = live ? rec_off[r] : 0u;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // two steps ahead: a wave walks its 8 records' chunks in ~nchunks/8 dependent steps, and small sets have few waves
     uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
+    uint4 nslot2 = (live && cl + 8 < nchunks) ? slots[(size_t)(cl + 8) * npad + r] : zero4;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
         const uint32_t c = c0 + cl;
         const uint4 slot = nslot;
-        if (c0 + 8 < nchunks)
-            nslot = (live && c + 8 < nchunks) ? slots[(size_t)(c + 8) * npad + r] : zero4;
+        nslot = nslot2;
+        if (c0 + 16 < nchunks)
+            nslot2 = (live && c + 16 < nchunks) ? slots[(size_t)(c + 16) * npad + r] : zero4;
         const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w};
         const uint32_t cnt_all = slot.x & 0xFFu;
         const bool big = cnt_all > kSlotEntries;
