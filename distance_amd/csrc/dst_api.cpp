@@ -694,8 +694,17 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             rc = ensure_aconst(ctx, rows, cols, fam, wide, stream);
         const void *d_tiles = nullptr;
         uint32_t ntiles = 0;
+        // rows per tile: 32, fewer for launches that would not fill the GPU a few times over (256 CUs x 3 workgroups:
+        // a 10,000-record job is 800 tiles of 32 rows — one round and a nearly empty second one)
+        uint32_t rows_per_tile = kConsensusRowsPerTile;
+        {
+            const uint64_t n_panels = (cols.n + kPanelCols - 1) / kPanelCols;
+            auto tiles_at = [&](uint32_t r) { return n_panels * ((re - rb + r - 1) / r) / (square ? 2 : 1); };
+            while (rows_per_tile > 8 && tiles_at(rows_per_tile) < 8 * 768)
+                rows_per_tile /= 2;
+        }
         if (!rc)
-            rc = prepare_schedule(ctx, square, rb, re, cols.n, (int)kConsensusRowsPerTile, -1, stream, &d_tiles, &ntiles);
+            rc = prepare_schedule(ctx, square, rb, re, cols.n, (int)rows_per_tile, -1, stream, &d_tiles, &ntiles);
         if (rc)
             return rc;
         const void *d_hot = nullptr;
