@@ -132,3 +132,35 @@ def test_root_share_balances_the_root_finalisation():
         assert abs(mine[k] - t_root) / t_root < 0.01      # everybody finishes together
     rows, o2 = chunked_layout(n, world, 8, first_share=f0)
     assert [x[0] for x in rows] == bounds[:-1] and [x[-1] for x in rows] == bounds[1:]
+
+
+def test_balanced_bounds_equalise_the_ranks():
+    """bench.py's sharded N>1 partition: preparation x records held + pair time x pairs equal over the ranks (the rank
+    that starts at row r0 holds records r0..n), monotone bounds from 0 to n, degenerate inputs included."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    start, end = src.index("def balanced_bounds"), src.index("def verify_rows")
+
+    class DA:
+        @staticmethod
+        def square_row_start(n, i):
+            return i * (2 * n - i - 1) // 2
+
+    ns = {"da": DA}
+    exec("from __future__ import annotations\n" + src[start:end], ns)
+    balanced_bounds = ns["balanced_bounds"]
+    assert spec is not None
+    n, prep, pair = 50_000, 0.9e-3 / 50_000, 2.1e-3 / 1.25e9
+    for world in (2, 3, 4, 8):
+        b = balanced_bounds(n, world, prep, pair)
+        assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:])) and len(b) == world + 1
+        t = [prep * (n - b[k]) + pair * (DA.square_row_start(n, b[k + 1]) - DA.square_row_start(n, b[k])) for k in range(world)]
+        assert max(t) - min(t) < 0.02 * max(t), (world, b, t)
+    # no preparation cost: equal pair counts; tiny sets: still a partition of [0, n]
+    b = balanced_bounds(1000, 4, 0.0, 1e-9)
+    pairs = [DA.square_row_start(1000, b[k + 1]) - DA.square_row_start(1000, b[k]) for k in range(4)]
+    assert max(pairs) - min(pairs) <= 2 * 1000
+    for nn, w in ((2, 2), (3, 8), (10, 3)):
+        b = balanced_bounds(nn, w, 1e-6, 1e-6)
+        assert b[0] == 0 and b[-1] == nn and all(x <= y for x, y in zip(b, b[1:])) and len(b) == w + 1
