@@ -205,14 +205,15 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     int rc = pack_queue(ctx, s, d_codes, n, len, row_stride, d_counts, ctx->d_first_bad, stream, want_lists);
     if (rc)
         return rc;
-    unsigned long long first_bad = 0, totals[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof first_bad, hipMemcpyDeviceToHost,
-                                stream));
-    if (want_lists) {
-        HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(ctx, hipMemcpyAsync(totals, s.rec.pre_totals, sizeof totals, hipMemcpyDeviceToHost, stream));
-    }
+    // the device writes its report (first invalid byte, statistics, totals) into page-locked host memory: one wait
+    HIP_TRY(ctx, launch_report(ctx->d_first_bad,
+                               want_lists ? reinterpret_cast<const unsigned long long *>(s.ref.stats) : nullptr,
+                               want_lists ? s.rec.pre_totals : nullptr, ctx->d_report, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
+    const unsigned long long first_bad = ctx->h_report[0], totals[2] = {ctx->h_report[9], ctx->h_report[10]};
+    if (want_lists)
+        for (int k = 0; k < 8; ++k)
+            s.ref.h_stats[k] = ctx->h_report[1 + k];
     if (first_bad != ~0ull)
         return invalid_code_error(ctx, first_bad, len);
     s.loaded = true;
@@ -477,15 +478,17 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
     unsigned long long total = 0;
+    const uint32_t *scan_src0 = nullptr, *scan_src1 = nullptr;
     const bool from_pack = &s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch;
     if (from_pack) {
         // the pack counted the list lengths against this very reference: no pass over the planes, no round trip
-        HIP_TRY(ctx, hipMemcpyAsync(s.rec.off, s.rec.pre_cold, (s.n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        // (the scan below reads the counts where the pack left them)
         total = s.rec.pre_total_cold;
         if (!without_hot && s.rec.pre_total_hot) {
-            HIP_TRY(ctx, launch_add_u32(s.rec.off, s.rec.pre_hot, s.n, stream));
+            scan_src1 = s.rec.pre_hot;
             total += s.rec.pre_total_hot;
         }
+        scan_src0 = s.rec.pre_cold;
     } else {
         HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
         HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, nullptr, ctx->d_total, stream));
@@ -503,7 +506,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, cap * sizeof(uint32_t));
     if (rc)
         return rc;
-    HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream));
+    HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream, scan_src0, scan_src1));
     if (from_pack)   // the entries are in the pack's slots already
         HIP_TRY(ctx, launch_slot_fill(s, refset.ref.planes, refset.ref.hot_planes, without_hot, s.rec.off, s.rec.ent,
                                       want_sites ? s.rec.col : nullptr, stream));
@@ -957,6 +960,10 @@ int dst_create(int device, dst_ctx **out)
             return bail(c, e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c->d_first_bad, sizeof(unsigned long long))) != hipSuccess)
         return bail(c, e, "hipMalloc");
+    if ((e = hipHostMalloc((void **)&c->h_report, 16 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return bail(c, e, "hipHostMalloc");
+    if ((e = hipHostGetDevicePointer((void **)&c->d_report, c->h_report, 0)) != hipSuccess)
+        return bail(c, e, "hipHostGetDevicePointer");
     if ((e = hipEventCreateWithFlags(&c->scratch_free, hipEventDisableTiming)) != hipSuccess)
         return bail(c, e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->hot_free, hipEventDisableTiming)) != hipSuccess)
@@ -1001,6 +1008,8 @@ int dst_destroy(dst_ctx *ctx)
             (void)hipEventDestroy(r.event);
     if (ctx->d_first_bad)
         (void)hipFree(ctx->d_first_bad);
+    if (ctx->h_report)
+        (void)hipHostFree(ctx->h_report);
     for (auto &ev : ctx->ev)
         if (ev)
             (void)hipEventDestroy(ev);

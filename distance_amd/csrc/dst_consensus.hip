@@ -298,6 +298,45 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
         out[((size_t)p * hot_chunks + hc) * hot_npad + r] = make_uint4(o[p][0], o[p][1], o[p][2], o[p][3]);
 }
 
+// The entries of ONE (record rs, chunk cs) written by the whole wave, two sites per lane, from `out0` on in ascending
+// site order.  For chunks with many differences (a run of N, a gap): left to its own lane such a chunk is a serial loop
+// over up to 128 sites, and the longest run of one record then sets the whole kernel's time.  Wave-uniform arguments.
+__device__ __forceinline__ void emit_chunk_by_wave(const uint4 *__restrict__ planes, const uint4 *__restrict__ ref_planes,
+                                                   const uint4 *__restrict__ hot_planes, bool skip_nclass, size_t ps,
+                                                   uint32_t nchunks, uint32_t npad, uint32_t rs, uint32_t cs, uint32_t out0,
+                                                   uint32_t lane, uint32_t *__restrict__ rec_ent, uint16_t *__restrict__ rec_col)
+{
+    const uint32_t w = lane >> 4, b0 = (lane & 15u) * 2u;
+    const size_t wa = ((size_t)cs * npad + rs) * 4u + w;
+    const uint32_t *const pw = reinterpret_cast<const uint32_t *>(planes);
+    const uint32_t *const rw = reinterpret_cast<const uint32_t *>(ref_planes);
+    const uint32_t a = pw[PL_A * ps * 4u + wa], g = pw[PL_G * ps * 4u + wa], cc = pw[PL_C * ps * 4u + wa], t = pw[PL_T * ps * 4u + wa];
+    const uint32_t ra = rw[(size_t)cs * 4u + w], rg = rw[((size_t)nchunks + cs) * 4u + w],
+                   rc = rw[(2 * (size_t)nchunks + cs) * 4u + w], rt = rw[(3 * (size_t)nchunks + cs) * 4u + w];
+    uint32_t dm = (a ^ ra) | (g ^ rg) | (cc ^ rc) | (t ^ rt);
+    if (hot_planes)
+        dm &= ~reinterpret_cast<const uint32_t *>(hot_planes)[(size_t)cs * 4u + w];
+    if (skip_nclass)
+        dm &= ~(a & g & cc & t);
+    // entries before this lane's sites: the words below + the bits below in its own word
+    const uint32_t pcw = (uint32_t)__builtin_popcount(dm);
+    const uint32_t p0 = __shfl(pcw, 0), p1 = __shfl(pcw, 16), p2 = __shfl(pcw, 32);
+    uint32_t pos = out0 + (w > 0 ? p0 : 0u) + (w > 1 ? p1 : 0u) + (w > 2 ? p2 : 0u) +
+                   (uint32_t)__builtin_popcount(dm & ((1u << b0) - 1u));
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+        const uint32_t bit = b0 + k;
+        if (dm >> bit & 1u) {
+            const uint32_t nib = ((a >> bit) & 1u) << 3 | ((g >> bit) & 1u) << 2 | ((cc >> bit) & 1u) << 1 | ((t >> bit) & 1u);
+            const uint32_t rnib = ((ra >> bit) & 1u) << 3 | ((rg >> bit) & 1u) << 2 | ((rc >> bit) & 1u) << 1 | ((rt >> bit) & 1u);
+            if (rec_col)
+                rec_col[pos] = (uint16_t)(rs & (kPanelCols - 1u));
+            rec_ent[pos] = (cs * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
+            ++pos;
+        }
+    }
+}
+
 // =============================================================================================
 // difference lists
 // =============================================================================================
@@ -373,7 +412,17 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
         up = __shfl_up(incl, 32);
         if (cl >= 4) incl += up;
         const uint32_t tot = __shfl(incl, 56 + rl);
-        if (pc) {
+        const bool by_wave = FILL && pc > kSlotEntries;   // many differences in one chunk: the whole wave writes them
+        if constexpr (FILL) {
+            const uint32_t at0 = base0 + run + (incl - pc);
+            for (unsigned long long todo = __ballot(by_wave); todo;) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                emit_chunk_by_wave(planes, ref_planes, hot_planes, skip_nclass != 0, ps, nchunks, npad, wave * 8u + (src & 7u),
+                                   c0 + (src >> 3), __shfl(at0, src), lane, rec_ent, rec_col);
+            }
+        }
+        if (pc && !by_wave) {
             uint32_t at = base0 + run + (incl - pc);
             const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
             const uint32_t aw[4] = {A.x, A.y, A.z, A.w}, gw[4] = {G.x, G.y, G.z, G.w};
@@ -414,54 +463,56 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
     }
 }
 
-// The fill pass from the pack's slots: same wave layout and output as index_kernel<true> (8 records x 8 chunks per
-// step, ascending site order), but a (record, chunk) is one 16-byte slot that already holds its entries — a quarter
-// of the four planes' bytes.  A chunk with more than kSlotEntries differences goes back to the planes.
+// The fill pass from the pack's slots: same output as index_kernel<true> (ascending site order), but a (record, chunk)
+// is one 16-byte slot that already holds its entries — a quarter of the four planes' bytes.  A chunk with more than
+// kSlotEntries differences goes back to the planes.
+// A wave = (64 / CLN) records x CLN chunks per step.  8 x 8 reads 128 contiguous bytes per chunk (what a big set
+// wants); a small set has too few waves that way, each a chain of nchunks / 8 steps of ~400 instructions (10,000 x
+// 30,000: 1,250 waves on 1,024 SIMDs, 78 us), so it takes 2 records x 32 chunks: four times the waves, a quarter of
+// the steps.  WITHOUT_HOT (the hybrid path's lists) filters entries; without it an entry's place is a constant offset.
+template <uint32_t CLN, bool WITHOUT_HOT>
 __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict__ slots, const uint4 *__restrict__ planes,
                                                         const uint4 *__restrict__ ref_planes,
-                                                        const uint4 *__restrict__ hot_planes, int without_hot, uint32_t n,
+                                                        const uint4 *__restrict__ hot_planes, uint32_t n,
                                                         uint32_t nchunks, uint32_t npad,
                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
                                                         uint16_t *__restrict__ rec_col)
 {
+    constexpr uint32_t RLN = 64u / CLN;
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t rl = lane & 7u, cl = lane >> 3;
-    const uint32_t r = wave * 8u + rl;
+    const uint32_t rl = lane % RLN, cl = lane / RLN;
+    const uint32_t r = wave * RLN + rl;
     const bool live = r < n;
     const size_t ps = (size_t)nchunks * npad;
     uint32_t run = 0;
     const uint32_t base0 = live ? rec_off[r] : 0u;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    // two steps ahead: a wave walks its 8 records' chunks in ~nchunks/8 dependent steps, and small sets have few waves
+    const uint16_t colv = (uint16_t)(r & (kPanelCols - 1u));
+    // two steps ahead
     uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
-    uint4 nslot2 = (live && cl + 8 < nchunks) ? slots[(size_t)(cl + 8) * npad + r] : zero4;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {
+    uint4 nslot2 = (live && cl + CLN < nchunks) ? slots[(size_t)(cl + CLN) * npad + r] : zero4;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += CLN) {
         const uint32_t c = c0 + cl;
         const uint4 slot = nslot;
         nslot = nslot2;
-        if (c0 + 16 < nchunks)
-            nslot2 = (live && c + 16 < nchunks) ? slots[(size_t)(c + 16) * npad + r] : zero4;
+        if (c0 + 2 * CLN < nchunks)
+            nslot2 = (live && c + 2 * CLN < nchunks) ? slots[(size_t)(c + 2 * CLN) * npad + r] : zero4;
         const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w};
         const uint32_t cnt_all = slot.x & 0xFFu;
         const bool big = cnt_all > kSlotEntries;
         // entries this lane emits: from the slot, or (big) from the planes
         uint32_t pc = 0;
-        uint4 A = zero4, G = zero4, C = zero4, T = zero4, d = zero4, rA = zero4, rG = zero4, rC = zero4, rT = zero4;
         if (big) {
             const size_t at = (size_t)c * npad + r;
-            A = planes[PL_A * ps + at];
-            G = planes[PL_G * ps + at];
-            C = planes[PL_C * ps + at];
-            T = planes[PL_T * ps + at];
-            rA = ref_planes[c];
-            rG = ref_planes[nchunks + c];
-            rC = ref_planes[2 * (size_t)nchunks + c];
-            rT = ref_planes[3 * (size_t)nchunks + c];
+            const uint4 A = planes[PL_A * ps + at], G = planes[PL_G * ps + at], C = planes[PL_C * ps + at], T = planes[PL_T * ps + at];
+            const uint4 rA = ref_planes[c], rG = ref_planes[nchunks + c], rC = ref_planes[2 * (size_t)nchunks + c],
+                        rT = ref_planes[3 * (size_t)nchunks + c];
+            uint4 d;
             d.x = (A.x ^ rA.x) | (G.x ^ rG.x) | (C.x ^ rC.x) | (T.x ^ rT.x);
             d.y = (A.y ^ rA.y) | (G.y ^ rG.y) | (C.y ^ rC.y) | (T.y ^ rT.y);
             d.z = (A.z ^ rA.z) | (G.z ^ rG.z) | (C.z ^ rC.z) | (T.z ^ rT.z);
             d.w = (A.w ^ rA.w) | (G.w ^ rG.w) | (C.w ^ rC.w) | (T.w ^ rT.w);
-            if (without_hot) {
+            if (WITHOUT_HOT) {
                 const uint4 h = hot_planes[c];
                 d.x &= ~h.x;
                 d.y &= ~h.y;
@@ -469,53 +520,56 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                 d.w &= ~h.w;
             }
             pc = popc4(d);
-        } else {
+        } else if (WITHOUT_HOT) {
 #pragma unroll
             for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                 const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
-                pc += (k <= cnt_all && !(without_hot && (e >> 14 & 1u))) ? 1u : 0u;
+                pc += (k <= cnt_all && !(e >> 14 & 1u)) ? 1u : 0u;
             }
+        } else {
+            pc = cnt_all;
         }
-        uint32_t incl = pc, up;
-        up = __shfl_up(incl, 8);
-        if (cl >= 1) incl += up;
-        up = __shfl_up(incl, 16);
-        if (cl >= 2) incl += up;
-        up = __shfl_up(incl, 32);
-        if (cl >= 4) incl += up;
-        const uint32_t tot = __shfl(incl, 56 + rl);
-        if (pc) {
-            uint32_t at = base0 + run + (incl - pc);
-            const uint16_t colv = (uint16_t)(r & (kPanelCols - 1u));
-            if (big) {
-                const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-                const uint32_t aw[4] = {A.x, A.y, A.z, A.w}, gw[4] = {G.x, G.y, G.z, G.w};
-                const uint32_t cw[4] = {C.x, C.y, C.z, C.w}, tw[4] = {T.x, T.y, T.z, T.w};
-                const uint32_t raw[4] = {rA.x, rA.y, rA.z, rA.w}, rgw[4] = {rG.x, rG.y, rG.z, rG.w};
-                const uint32_t rcw[4] = {rC.x, rC.y, rC.z, rC.w}, rtw[4] = {rT.x, rT.y, rT.z, rT.w};
+        // inclusive scan over the chunk lanes of a record (lanes RLN apart)
+        uint32_t incl = pc;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    uint32_t m = dw[w];
-                    while (m) {
-                        const uint32_t bit = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1;
-                        const uint32_t nib = ((aw[w] >> bit) & 1u) << 3 | ((gw[w] >> bit) & 1u) << 2 |
-                                             ((cw[w] >> bit) & 1u) << 1 | ((tw[w] >> bit) & 1u);
-                        const uint32_t rnib = ((raw[w] >> bit) & 1u) << 3 | ((rgw[w] >> bit) & 1u) << 2 |
-                                              ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
-                        if (rec_col)
-                            rec_col[at] = colv;
-                        rec_ent[at++] = (c * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
-                    }
-                }
-            } else {
+        for (uint32_t o = RLN; o < 64u; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t tot = __shfl(incl, 64u - RLN + rl);
+        const uint32_t at0 = base0 + run + (incl - pc);
+        // a chunk that did not fit its slot is emitted by the whole wave (50 of 72 us at 10,000 x 30,000 were the serial
+        // loops of the few lanes holding a run of N)
+        for (unsigned long long todo = __ballot(big && pc != 0); todo;) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            emit_chunk_by_wave(planes, ref_planes, WITHOUT_HOT ? hot_planes : nullptr, false, ps, nchunks, npad,
+                               wave * RLN + src % RLN, c0 + src / RLN, __shfl(at0, src), lane, rec_ent, rec_col);
+        }
+        if (pc && !big) {
+            uint32_t at = at0;
+            if (WITHOUT_HOT) {
 #pragma unroll
                 for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                     const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
-                    if (k <= cnt_all && !(without_hot && (e >> 14 & 1u))) {
+                    if (k <= cnt_all && !(e >> 14 & 1u)) {
                         if (rec_col)
                             rec_col[at] = colv;
                         rec_ent[at++] = (c * kChunkSites + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
+                    }
+                }
+            } else {
+                // entry k of the slot goes to at + k - 1: constant offsets from one address
+                uint32_t *const ep = rec_ent + at;
+                uint16_t *const cp = rec_col ? rec_col + at : nullptr;
+                const uint32_t site0 = c * kChunkSites;
+#pragma unroll
+                for (uint32_t k = 1; k <= kSlotEntries; ++k) {
+                    const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    if (k <= cnt_all) {
+                        if (cp)
+                            cp[k - 1] = colv;
+                        ep[k - 1] = (site0 + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
                     }
                 }
             }
@@ -642,15 +696,17 @@ __global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint3
 // =============================================================================================
 constexpr uint32_t kScanPerBlock = 2048;  // 256 threads x 8
 
+// src0 (+ src1) given: the values come from there and `data` only receives the scan (no copy / add pass before it)
 __global__ __launch_bounds__(256) void scan_block_kernel(uint32_t *__restrict__ data, size_t n,
-                                                         uint32_t *__restrict__ block_sums)
+                                                         uint32_t *__restrict__ block_sums,
+                                                         const uint32_t *__restrict__ src0, const uint32_t *__restrict__ src1)
 {
     __shared__ uint32_t wave_tot[4];
     const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 8;
     uint32_t v[8], sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        v[k] = base + k < n ? data[base + k] : 0u;
+        v[k] = base + k < n ? (src0 ? src0[base + k] + (src1 ? src1[base + k] : 0u) : data[base + k]) : 0u;
         sum += v[k];
     }
     uint32_t incl = sum, up;
@@ -707,6 +763,21 @@ __global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restric
         if (s1)
             atomicAdd(&totals[1], s1);
     }
+}
+
+// What the host wants to know after an upload, gathered into one page-locked host block by the device itself (three
+// blocking device-to-host copies of 8-64 bytes cost ~20 us each: a fifth of a 10,000-record step)
+__global__ __launch_bounds__(64) void report_kernel(const unsigned long long *__restrict__ first_bad,
+                                                    const unsigned long long *__restrict__ stats,
+                                                    const unsigned long long *__restrict__ totals, unsigned long long *report)
+{
+    const uint32_t t = threadIdx.x;
+    if (t == 0)
+        report[0] = *first_bad;
+    else if (t <= 8)
+        report[t] = stats ? stats[t - 1] : 0ull;
+    else if (t < (uint32_t)kReportWords)
+        report[t] = totals ? totals[t - 9] : 0ull;
 }
 
 __global__ __launch_bounds__(256) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
@@ -1476,9 +1547,25 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uin
 hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
                             uint32_t *rec_off, uint32_t *rec_ent, uint16_t *rec_col, hipStream_t stream)
 {
-    hipLaunchKernelGGL(slot_fill_kernel, dim3((unsigned)((set.n + 31) / 32)), dim3(256), 0, stream, set.rec.pre_slots, set.planes,
-                       ref_planes, hot_planes, without_hot ? 1 : 0, (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad,
-                       rec_off, rec_ent, rec_col);
+    // waves of 8 records x 8 chunks when that makes enough of them, else 4 x 16 or 2 x 32 (see the kernel)
+    const uint32_t n = (uint32_t)set.n, nch = (uint32_t)set.nchunks, npad = (uint32_t)set.npad;
+    auto go = [&](auto cln, auto wh) {
+        constexpr uint32_t CLN = decltype(cln)::value;
+        constexpr uint32_t per_block = 4u * (64u / CLN);
+        hipLaunchKernelGGL((slot_fill_kernel<CLN, decltype(wh)::value>), dim3((n + per_block - 1) / per_block), dim3(256), 0, stream,
+                           set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, rec_col);
+    };
+    using std::integral_constant;
+    const uint32_t cln = n >= 32768 ? 8u : n >= 16384 ? 16u : 32u;
+    if (without_hot) {
+        if (cln == 8) go(integral_constant<uint32_t, 8>{}, std::true_type{});
+        else if (cln == 16) go(integral_constant<uint32_t, 16>{}, std::true_type{});
+        else go(integral_constant<uint32_t, 32>{}, std::true_type{});
+    } else {
+        if (cln == 8) go(integral_constant<uint32_t, 8>{}, std::false_type{});
+        else if (cln == 16) go(integral_constant<uint32_t, 16>{}, std::false_type{});
+        else go(integral_constant<uint32_t, 32>{}, std::false_type{});
+    }
     return hipGetLastError();
 }
 
@@ -1501,12 +1588,13 @@ size_t scan_tmp_words(size_t n)
     return words + 2;
 }
 
-hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream)
+hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0,
+                                 const uint32_t *src1)
 {
     if (n == 0)
         return hipSuccess;
     const size_t nb = (n + kScanPerBlock - 1) / kScanPerBlock;
-    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, stream, data, n, tmp);
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, stream, data, n, tmp, src0, src1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || nb == 1)
         return e;
@@ -1520,6 +1608,13 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream)
 {
     hipLaunchKernelGGL(sum2_u32_kernel, dim3((unsigned)std::min<size_t>(256, (n + 255) / 256 + 1)), dim3(256), 0, stream, a0, a1, n, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const unsigned long long *totals,
+                         unsigned long long *report, hipStream_t stream)
+{
+    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, first_bad, stats, totals, report);
     return hipGetLastError();
 }
 

@@ -16,6 +16,9 @@ struct dst_ctx {
     uint8_t *stage = nullptr;
     size_t stage_bytes = 0;
     unsigned long long *d_first_bad = nullptr;
+    // what an upload reports to the host (first invalid byte, the sample's statistics, the list totals): written by the
+    // device into this page-locked block, so the upload's one synchronisation needs no device-to-host copy
+    unsigned long long *h_report = nullptr, *d_report = nullptr;
     // tile schedules already on the device, keyed by the launch geometry (multi-GPU runs cycle
     // through a few sub-slab ranges every step: no host sync or H2D on a hit)
     struct Schedule {

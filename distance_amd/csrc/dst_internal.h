@@ -216,9 +216,14 @@ hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const
 hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream);
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
-hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream);
+// exclusive scan of data[0..n) in place; src0 (+ src1) given: of src0[i] (+ src1[i]) into data
+hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0 = nullptr,
+                                 const uint32_t *src1 = nullptr);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
 hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream);   // dst[i] += src[i]
+constexpr int kReportWords = 11;   // [0] first invalid byte, [1..8] the sample's statistics, [9..10] list totals
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const unsigned long long *totals,
+                         unsigned long long *report, hipStream_t stream);
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
