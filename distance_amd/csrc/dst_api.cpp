@@ -52,7 +52,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.col, s.rec.pre_cold, s.rec.pre_slots,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.range_start, s.rec.pre_cold, s.rec.pre_slots,
                     s.site.inl, s.site.ent, s.aconst};
     for (void *b : bufs)
         if (b)
@@ -491,7 +491,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         scan_src0 = s.rec.pre_cold;
     } else {
         HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
-        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, nullptr, ctx->d_total, stream));
+        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, ctx->d_total, stream));
         HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
     }
@@ -501,18 +501,19 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     const size_t cap = std::max<size_t>(total, 1);
     rc = ensure_bytes(ctx, (void **)&s.rec.ent, &s.rec.ent_cap, (cap + 4) * sizeof(uint32_t));  // 16-byte reads past the end
     if (!rc && want_sites)
-        rc = ensure_bytes(ctx, (void **)&s.rec.col, &s.rec.col_cap, (cap + 4) * sizeof(uint16_t));
-    if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, cap * sizeof(uint32_t));
+    if (!rc && want_sites)
+        rc = ensure_bytes(ctx, (void **)&s.rec.range_start, &s.rec.range_cap,
+                          ((s.nchunks * kChunkSites + kBucketSites - 1) / kBucketSites) * s.npad * sizeof(uint32_t));
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream, scan_src0, scan_src1));
     if (from_pack)   // the entries are in the pack's slots already
         HIP_TRY(ctx, launch_slot_fill(s, refset.ref.planes, refset.ref.hot_planes, without_hot, s.rec.off, s.rec.ent,
-                                      want_sites ? s.rec.col : nullptr, stream));
+                                      want_sites ? s.rec.range_start : nullptr, stream));
     else
-        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent,
-                                  want_sites ? s.rec.col : nullptr, ctx->d_total, stream));
+        HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, true, false, s.rec.off, s.rec.ent, ctx->d_total, stream,
+                                  want_sites ? s.rec.range_start : nullptr));
     if (want_sites)
         HIP_TRY(ctx, launch_site_buckets(s, n_panels, d_ovf_n, stream));
     // runs queued on other streams wait for this on the device
@@ -1237,7 +1238,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     if (e == hipSuccess)
         e = hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, false, true, d_off, nullptr, nullptr, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, false, true, d_off, nullptr, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream);
@@ -1265,7 +1266,7 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
         return done(DST_OK);
     e = hipMalloc((void **)&d_ent, total * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = launch_index(s, d_ref, nullptr, true, true, d_off, d_ent, nullptr, ctx->d_total,
+        e = launch_index(s, d_ref, nullptr, true, true, d_off, d_ent, ctx->d_total,
                          ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(sites, d_ent, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

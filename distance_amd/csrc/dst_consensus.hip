@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
 __device__ __forceinline__ void emit_chunk_by_wave(const uint4 *__restrict__ planes, const uint4 *__restrict__ ref_planes,
                                                    const uint4 *__restrict__ hot_planes, bool skip_nclass, size_t ps,
                                                    uint32_t nchunks, uint32_t npad, uint32_t rs, uint32_t cs, uint32_t out0,
-                                                   uint32_t lane, uint32_t *__restrict__ rec_ent, uint16_t *__restrict__ rec_col)
+                                                   uint32_t lane, uint32_t *__restrict__ rec_ent)
 {
     const uint32_t w = lane >> 4, b0 = (lane & 15u) * 2u;
     const size_t wa = ((size_t)cs * npad + rs) * 4u + w;
@@ -329,8 +329,6 @@ __device__ __forceinline__ void emit_chunk_by_wave(const uint4 *__restrict__ pla
         if (dm >> bit & 1u) {
             const uint32_t nib = ((a >> bit) & 1u) << 3 | ((g >> bit) & 1u) << 2 | ((cc >> bit) & 1u) << 1 | ((t >> bit) & 1u);
             const uint32_t rnib = ((ra >> bit) & 1u) << 3 | ((rg >> bit) & 1u) << 2 | ((rc >> bit) & 1u) << 1 | ((rt >> bit) & 1u);
-            if (rec_col)
-                rec_col[pos] = (uint16_t)(rs & (kPanelCols - 1u));
             rec_ent[pos] = (cs * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
             ++pos;
         }
@@ -351,7 +349,7 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                                     const uint4 *__restrict__ hot_planes, uint32_t n,
                                                     uint32_t nchunks, uint32_t npad, int skip_nclass,
                                                     uint32_t *__restrict__ rec, uint32_t *__restrict__ rec_ent,
-                                                    uint16_t *__restrict__ rec_col, unsigned long long *__restrict__ total)
+                                                    unsigned long long *__restrict__ total, uint32_t *__restrict__ range_start)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t rl = lane & 7u, cl = lane >> 3;
@@ -415,11 +413,14 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
         const bool by_wave = FILL && pc > kSlotEntries;   // many differences in one chunk: the whole wave writes them
         if constexpr (FILL) {
             const uint32_t at0 = base0 + run + (incl - pc);
+            static_assert(kBucketSites == 8 * kChunkSites, "a step of this kernel is one range of site_bucket_kernel");
+            if (range_start && live && cl == 0)
+                range_start[(size_t)(c0 >> 3) * npad + r] = at0;
             for (unsigned long long todo = __ballot(by_wave); todo;) {
                 const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 emit_chunk_by_wave(planes, ref_planes, hot_planes, skip_nclass != 0, ps, nchunks, npad, wave * 8u + (src & 7u),
-                                   c0 + (src >> 3), __shfl(at0, src), lane, rec_ent, rec_col);
+                                   c0 + (src >> 3), __shfl(at0, src), lane, rec_ent);
             }
         }
         if (pc && !by_wave) {
@@ -441,8 +442,6 @@ __global__ __launch_bounds__(256) void index_kernel(const uint4 *__restrict__ pl
                                              ((cw[w] >> bit) & 1u) << 1 | ((tw[w] >> bit) & 1u);
                         const uint32_t rnib = ((raw[w] >> bit) & 1u) << 3 | ((rgw[w] >> bit) & 1u) << 2 |
                                               ((rcw[w] >> bit) & 1u) << 1 | ((rtw[w] >> bit) & 1u);
-                        if (rec_col)   // a column set: the entry's record within its panel, for site_bucket_kernel
-                            rec_col[at] = (uint16_t)(r & (kPanelCols - 1u));
                         rec_ent[at++] = s | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
                     }
                 }
@@ -476,7 +475,7 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                                                         const uint4 *__restrict__ hot_planes, uint32_t n,
                                                         uint32_t nchunks, uint32_t npad,
                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
-                                                        uint16_t *__restrict__ rec_col)
+                                                        uint32_t *__restrict__ range_start)
 {
     constexpr uint32_t RLN = 64u / CLN;
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -487,7 +486,6 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
     uint32_t run = 0;
     const uint32_t base0 = live ? rec_off[r] : 0u;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const uint16_t colv = (uint16_t)(r & (kPanelCols - 1u));
     // two steps ahead
     uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
     uint4 nslot2 = (live && cl + CLN < nchunks) ? slots[(size_t)(cl + CLN) * npad + r] : zero4;
@@ -538,13 +536,16 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
         }
         const uint32_t tot = __shfl(incl, 64u - RLN + rl);
         const uint32_t at0 = base0 + run + (incl - pc);
+        // where the record's list crosses a multiple of kBucketSites (site_bucket_kernel's pieces)
+        if (range_start && live && c < nchunks && c % (kBucketSites / kChunkSites) == 0)
+            range_start[(size_t)(c / (kBucketSites / kChunkSites)) * npad + r] = at0;
         // a chunk that did not fit its slot is emitted by the whole wave (50 of 72 us at 10,000 x 30,000 were the serial
         // loops of the few lanes holding a run of N)
         for (unsigned long long todo = __ballot(big && pc != 0); todo;) {
             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
             emit_chunk_by_wave(planes, ref_planes, WITHOUT_HOT ? hot_planes : nullptr, false, ps, nchunks, npad,
-                               wave * RLN + src % RLN, c0 + src / RLN, __shfl(at0, src), lane, rec_ent, rec_col);
+                               wave * RLN + src % RLN, c0 + src / RLN, __shfl(at0, src), lane, rec_ent);
         }
         if (pc && !big) {
             uint32_t at = at0;
@@ -553,22 +554,17 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                 for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                     const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
                     if (k <= cnt_all && !(e >> 14 & 1u)) {
-                        if (rec_col)
-                            rec_col[at] = colv;
                         rec_ent[at++] = (c * kChunkSites + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
                     }
                 }
             } else {
                 // entry k of the slot goes to at + k - 1: constant offsets from one address
                 uint32_t *const ep = rec_ent + at;
-                uint16_t *const cp = rec_col ? rec_col + at : nullptr;
                 const uint32_t site0 = c * kChunkSites;
 #pragma unroll
                 for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                     const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
                     if (k <= cnt_all) {
-                        if (cp)
-                            cp[k - 1] = colv;
                         ep[k - 1] = (site0 + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
                     }
                 }
@@ -583,66 +579,89 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
 // =============================================================================================
 // One block = one (panel of 2,048 records, range of kBucketSites sites): it owns the buckets of that piece, so
 // their sizes are LDS counters and their 32-byte lookup-table entries are assembled in LDS and leave as one
-// contiguous 32 KB piece — no global atomics, no scattered 2-byte writes into the table.  The block streams ALL
-// list entries of the panel's records (16-byte loads; the lists are 1/250 of the planes they were made from) and
-// keeps the ones of its sites; the record of an entry travels beside it (rec_col).
+// contiguous 32 KB piece — no global atomics, no scattered 2-byte writes into the table.  A record's list is in
+// ascending site order and the fill pass notes where it crosses every multiple of kBucketSites (range_start), so a
+// thread knows the piece of its record's list that lies in the block's sites (r02 first streamed ALL entries of the
+// panel through every block and kept 1 in 30: 16 dependent rounds of loads, 42 us a block) and walks up to kBucketWalk
+// entries of it; what a long piece (a run of N) has beyond those is shared out over a wave.
 //   table entry = 16 halfwords: [0] entries in the bucket (<= 2,048), [1..15] entries as record-in-panel | nibble << 11;
 //   a bucket of more than kInlineEvents entries keeps kInlineOverflowing of them inline, its last word is the place
 //   of the others in site_ent (record | nibble << 28).  Such buckets take a second pass over the lists, after the
 //   block has counted them and reserved room for all its overflow entries with ONE global atomic.
-constexpr uint32_t kBucketSites = 1024;
 constexpr uint32_t kBucketThreads = 1024;
 
+constexpr uint32_t kBucketWalk = 8;
 __global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint32_t *__restrict__ rec_off,
                                                                      const uint32_t *__restrict__ rec_ent,
-                                                                     const uint16_t *__restrict__ rec_col, uint32_t n,
-                                                                     uint32_t n_sites, uint4 *__restrict__ site_inl,
+                                                                     const uint32_t *__restrict__ range_start, uint32_t n,
+                                                                     uint32_t npad, uint32_t n_sites, uint4 *__restrict__ site_inl,
                                                                      uint32_t *__restrict__ site_ent,
                                                                      uint32_t *__restrict__ ovf_total)
 {
-    constexpr uint32_t NT = kBucketThreads, UNROLL = 4;
+    constexpr uint32_t NT = kBucketThreads, RPT = kPanelCols / NT;   // records per thread
     static_assert(NT == kBucketSites, "one bucket per thread in the offset scan");
+    static_assert(RPT * NT == kPanelCols, "every record of the panel has its thread");
     __shared__ uint32_t cnt[kBucketSites];
     __shared__ uint32_t ooff[kBucketSites];
     __shared__ __attribute__((aligned(16))) uint16_t tabl[kBucketSites][16];
     __shared__ uint32_t wave_tot[NT / 64];
     __shared__ uint32_t blk_base;
+    __shared__ uint32_t long_n, long_from[kPanelCols], long_to[kPanelCols];
+    __shared__ uint16_t long_rec[kPanelCols];
     const uint32_t panel = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t s0 = blockIdx.x * kBucketSites, ns = min(kBucketSites, n_sites - s0);
     const uint32_t r0 = panel * kPanelCols, nrec = min(kPanelCols, n - r0);
     cnt[tid] = 0;
+    if (tid == 0)
+        long_n = 0;
     for (uint32_t k = tid; k < kBucketSites * 2; k += NT)
         reinterpret_cast<uint4 *>(&tabl[0][0])[k] = make_uint4(0, 0, 0, 0);
+    // the piece of each of this thread's records' lists that lies in the block's sites: the fill pass noted where every
+    // record's list crosses a multiple of kBucketSites (range_start) — no search, and the piece's length is known
+    uint32_t from[RPT], to[RPT];
+#pragma unroll
+    for (uint32_t k = 0; k < RPT; ++k) {
+        const uint32_t rr = tid + k * NT;
+        from[k] = to[k] = 0;
+        if (rr < nrec) {
+            from[k] = range_start[(size_t)blockIdx.x * npad + r0 + rr];
+            to[k] = blockIdx.x + 1 < gridDim.x ? range_start[(size_t)(blockIdx.x + 1) * npad + r0 + rr] : rec_off[r0 + rr + 1];
+        }
+    }
     __syncthreads();
-    const uint32_t e0 = rec_off[r0], e1 = rec_off[r0 + nrec];
     // every list entry of the panel whose site is in this block's range: visit(site - s0, record in panel, nibble).
-    // UNROLL 16-byte loads in flight per thread (one at a time the loop is a chain of memory latencies).
-    auto stream_lists = [&](auto &&visit) {
-        for (uint32_t ib = (e0 & ~3u) + 4u * tid; ib < e1; ib += 4u * NT * UNROLL) {
-            uint4 v[UNROLL];
-            uint2 vc[UNROLL];
+    // first == true also notes the pieces that go on beyond a thread's kBucketWalk entries (the second pass reuses the notes)
+    auto for_each_entry = [&](bool first, auto &&visit) {
 #pragma unroll
-            for (uint32_t u = 0; u < UNROLL; ++u) {
-                const uint32_t i = ib + u * 4u * NT;   // (both arrays have 4 entries of slack at their ends)
-                v[u] = i < e1 ? *reinterpret_cast<const uint4 *>(rec_ent + i) : make_uint4(0, 0, 0, 0);
-                vc[u] = i < e1 ? *reinterpret_cast<const uint2 *>(rec_col + i) : make_uint2(0, 0);
+        for (uint32_t k = 0; k < RPT; ++k) {
+            const uint32_t rr = tid + k * NT;
+            uint32_t e[kBucketWalk];
+#pragma unroll
+            for (uint32_t j = 0; j < kBucketWalk; ++j)
+                e[j] = from[k] + j < to[k] ? rec_ent[from[k] + j] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kBucketWalk; ++j)
+                if (from[k] + j < to[k])
+                    visit((e[j] & kSiteMask) - s0, rr, e[j] >> kEntryShift);
+            if (first && from[k] + kBucketWalk < to[k]) {
+                const uint32_t q = atomicAdd(&long_n, 1u);
+                long_rec[q] = (uint16_t)rr;
+                long_from[q] = from[k] + kBucketWalk;
+                long_to[q] = to[k];
             }
-#pragma unroll
-            for (uint32_t u = 0; u < UNROLL; ++u) {
-                const uint32_t i = ib + u * 4u * NT;
-                const uint32_t ev[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                const uint32_t cv[4] = {vc[u].x & 0xFFFFu, vc[u].x >> 16, vc[u].y & 0xFFFFu, vc[u].y >> 16};
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t idx = i + j, sl = (ev[j] & kSiteMask) - s0;
-                    if (idx >= e0 && idx < e1 && sl < ns)
-                        visit(sl, cv[j], ev[j] >> kEntryShift);
-                }
+        }
+        __syncthreads();
+        const uint32_t nq = long_n;
+        for (uint32_t q = tid >> 6; q < nq; q += NT / 64) {   // a wave per piece: the pieces' loads overlap
+            const uint32_t rr = long_rec[q], hi = long_to[q];
+            for (uint32_t j = long_from[q] + lane; j < hi; j += 64u) {
+                const uint32_t ev = rec_ent[j];
+                visit((ev & kSiteMask) - s0, rr, ev >> kEntryShift);
             }
         }
     };
     // pass 1: sizes, and the entries of every bucket as if it fitted
-    stream_lists([&](uint32_t sl, uint32_t col, uint32_t nib) {
+    for_each_entry(true, [&](uint32_t sl, uint32_t col, uint32_t nib) {
         const uint32_t pos = atomicAdd(&cnt[sl], 1u);
         if (pos < kInlineEvents)
             tabl[sl][1 + pos] = (uint16_t)(col | nib << 11);
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint3
             *reinterpret_cast<uint32_t *>(&tabl[tid][14]) = ooff[tid];
         __syncthreads();
         // pass 2: the buckets that do not fit, again: kInlineOverflowing entries inline, the others to their place
-        stream_lists([&](uint32_t sl, uint32_t col, uint32_t nib) {
+        for_each_entry(false, [&](uint32_t sl, uint32_t col, uint32_t nib) {
             if (tabl[sl][0] <= kInlineEvents)
                 return;
             const uint32_t pos = atomicAdd(&cnt[sl], 1u);
@@ -757,11 +776,17 @@ __global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restric
         s0 += __shfl_xor(s0, o);
         s1 += __shfl_xor(s1, o);
     }
+    // one atomic per block and total (per wave they were 1,600 same-address atomics at 50,000 records: 12 us)
+    __shared__ unsigned long long part[4][2];
     if ((threadIdx.x & 63u) == 0) {
-        if (s0)
-            atomicAdd(&totals[0], s0);
-        if (s1)
-            atomicAdd(&totals[1], s1);
+        part[threadIdx.x >> 6][0] = s0;
+        part[threadIdx.x >> 6][1] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t)
+            atomicAdd(&totals[threadIdx.x], t);
     }
 }
 
@@ -1532,20 +1557,20 @@ hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint3
 }
 
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
-                        uint32_t *rec, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total, hipStream_t stream)
+                        uint32_t *rec, uint32_t *rec_ent, unsigned long long *total, hipStream_t stream, uint32_t *range_start)
 {
     const unsigned blocks = (unsigned)((set.n + 31) / 32);
     if (fill)
         hipLaunchKernelGGL(index_kernel<true>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
-                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, rec_col, total);
+                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, total, range_start);
     else
         hipLaunchKernelGGL(index_kernel<false>, dim3(blocks), dim3(256), 0, stream, set.planes, ref_planes, hot_planes,
-                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, rec_col, total);
+                           (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, skip_nclass ? 1 : 0, rec, rec_ent, total, range_start);
     return hipGetLastError();
 }
 
 hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
-                            uint32_t *rec_off, uint32_t *rec_ent, uint16_t *rec_col, hipStream_t stream)
+                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream)
 {
     // waves of 8 records x 8 chunks when that makes enough of them, else 4 x 16 or 2 x 32 (see the kernel)
     const uint32_t n = (uint32_t)set.n, nch = (uint32_t)set.nchunks, npad = (uint32_t)set.npad;
@@ -1553,7 +1578,7 @@ hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const
         constexpr uint32_t CLN = decltype(cln)::value;
         constexpr uint32_t per_block = 4u * (64u / CLN);
         hipLaunchKernelGGL((slot_fill_kernel<CLN, decltype(wh)::value>), dim3((n + per_block - 1) / per_block), dim3(256), 0, stream,
-                           set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, rec_col);
+                           set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, range_start);
     };
     using std::integral_constant;
     const uint32_t cln = n >= 32768 ? 8u : n >= 16384 ? 16u : 32u;
@@ -1573,7 +1598,7 @@ hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t
 {
     const uint32_t n_sites = (uint32_t)(set.nchunks * kChunkSites);
     hipLaunchKernelGGL(site_bucket_kernel, dim3((n_sites + kBucketSites - 1) / kBucketSites, n_panels), dim3(kBucketThreads), 0,
-                       stream, set.rec.off, set.rec.ent, set.rec.col, (uint32_t)set.n, n_sites, set.site.inl, set.site.ent,
+                       stream, set.rec.off, set.rec.ent, set.rec.range_start, (uint32_t)set.n, (uint32_t)set.npad, n_sites, set.site.inl, set.site.ent,
                        ovf_total);
     return hipGetLastError();
 }
@@ -1607,7 +1632,7 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
 
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sum2_u32_kernel, dim3((unsigned)std::min<size_t>(256, (n + 255) / 256 + 1)), dim3(256), 0, stream, a0, a1, n, totals);
+    hipLaunchKernelGGL(sum2_u32_kernel, dim3((unsigned)std::min<size_t>(256, (n + 1023) / 1024 + 1)), dim3(256), 0, stream, a0, a1, n, totals);
     return hipGetLastError();
 }
 

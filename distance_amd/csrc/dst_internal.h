@@ -46,6 +46,7 @@ constexpr uint32_t kBlockThreads = 256;
 //     h_k    = f_k(q,t) - f_k(q,c) - f_k(c,t) + f_k(c,c)
 // exact integers whatever c is; the work is proportional to the differences from c, not to L.
 constexpr uint32_t kPanelCols = 2048;      // column records per site bucket = width of the LDS accumulators
+constexpr uint32_t kBucketSites = 1024;    // sites per block of site_bucket_kernel: the lists' range_start marks are this far apart
 constexpr int kAccRows = 2;                // rows whose accumulators a workgroup holds at once
 constexpr uint32_t kTileRowsMax = 32;      // rows of one consensus-path tile (a multiple of kAccRows)
 constexpr uint32_t kEntryShift = 28;       // list entries: nibble in the top four bits
@@ -76,7 +77,6 @@ struct ConsensusRef {             // the reference sequence, sampled from the se
 struct RecordIndex {              // per record: the sites where it differs from the reference, ascending
     uint32_t *off = nullptr;      // [n + 1]
     uint32_t *ent = nullptr;      // site | class of the reference there << 25 | the record's nibble << 28
-    uint16_t *col = nullptr;      // column sets: the entry's record within its panel (read by site_bucket_kernel)
     // list lengths counted by the pack itself against the set's own reference (cold sites / hot sites apart), with
     // their sums {cold, hot} — valid while pre_epoch == the set's epoch
     uint4 *pre_slots = nullptr;   // [nchunks][npad] the entries themselves, by (record, chunk) (PackLists::slots)
@@ -86,7 +86,9 @@ struct RecordIndex {              // per record: the sites where it differs from
     size_t pre_cap = 0;
     uint64_t pre_epoch = 0, pre_total_cold = 0, pre_total_hot = 0;
     bool pre_valid = false;
-    size_t off_cap = 0, ent_cap = 0, col_cap = 0;
+    size_t off_cap = 0, ent_cap = 0, range_cap = 0;
+    // column sets: [ceil(nchunks / 8)][npad] where the record's list crosses every multiple of kBucketSites sites
+    uint32_t *range_start = nullptr;
     uint64_t total = 0;
     const void *ref_owner = nullptr;  // the DeviceSet whose reference these lists are relative to
     uint64_t ref_epoch = 0;
@@ -206,11 +208,11 @@ hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_compact(const DeviceSet &src, const uint32_t *hot_sites, uint32_t n_hot, DeviceSet &dst, hipStream_t stream);
 // hot_planes != NULL: sites whose bit is set are left out of the lists
 hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool fill, bool skip_nclass,
-                        uint32_t *rec_off_or_cnt, uint32_t *rec_ent, uint16_t *rec_col, unsigned long long *total,
-                        hipStream_t stream);
+                        uint32_t *rec_off_or_cnt, uint32_t *rec_ent, unsigned long long *total,
+                        hipStream_t stream, uint32_t *range_start = nullptr);
 // the same lists from the pack's slots (set.rec.pre_slots) instead of the planes; without_hot: leave the hot entries out
 hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
-                            uint32_t *rec_off, uint32_t *rec_ent, uint16_t *rec_col, hipStream_t stream);
+                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream);
 // a column set's site buckets from its lists (set.rec -> set.site); *ovf_total (zeroed by the caller) counts the
 // overflow entries placed in set.site.ent
 hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream);
