@@ -14,7 +14,7 @@ src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 OURS = ("consensus_pair_kernel", "pair_kernel", "finalize_kernel", "pack_kernel", "counts_kernel", "index_kernel",
         "ref_sample_kernel", "hot_list_kernel", "site_bucket_kernel", "slot_fill_kernel", "derive_kernel", "sum2_u32_kernel", "add_u32_kernel", "aconst_kernel",
-        "scan_block_kernel", "scan_add_kernel", "compact_kernel")
+        "scan_block_kernel", "scan_add_kernel", "compact_kernel", "report_kernel")
 
 
 def short(name):
