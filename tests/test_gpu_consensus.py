@@ -364,3 +364,38 @@ def test_a_lean_set_still_serves_every_path(eng):
             for m in want_tallies:
                 assert np.array_equal(eng.run_square(m, 5, 9, tallies=True), want_tallies[m]), (order, path, m)
     eng.set_path("auto")
+
+
+@pytest.mark.parametrize("n", [3000, 20000, 36000])
+def test_every_wave_shape_of_the_fill_pass(eng, n):
+    """The fill pass from the pack's slots runs as 2 x 32, 4 x 16 or 8 x 8 (records x chunks per wave) by the set's size,
+    hands chunks of more than 7 differences (runs of N, gaps) to the whole wave, and leaves the marks the bucket pass
+    cuts every record's list by.  Each shape, with long runs that cross chunk and 1,024-site boundaries and with runs
+    inside hot columns, must give the dense path's bits — through the fused preparation and through the plain one."""
+    L = 2300                                           # 18 chunks: three ranges of 1,024 sites, the last one partial
+    rng = np.random.default_rng(700 + n)
+    codes = low_diversity(n, L, 71 + n, subs=1.5e-3, p_n=5e-4, p_amb=1e-4)
+    for r in rng.choice(n, size=60, replace=False):    # runs of N / gap of 5..900 sites anywhere in the record
+        a = int(rng.integers(0, L - 5))
+        codes[r, a:a + int(rng.integers(5, 900))] = 240 if rng.random() < 0.7 else 244
+    codes[rng.random(n) < 0.2, 1000:1030] = 72         # hot columns straddling the 1,024 mark (hybrid path)
+    codes[n // 2, :] = 240                             # one record that differs everywhere
+    rows = sorted({0, 1, n // 2 - 1, n // 2, n - 2} | set(int(x) for x in rng.choice(n - 1, size=4)))
+    ref = da.Engine(0)
+    ref.set_path("dense")
+    ref.upload(0, codes)
+    want = {(m, r): ref.run_square(m, r, r + 1) for m in ("n_high", "raw", "tn93") for r in rows}
+    want_t = {r: ref.run_square("tn93", r, r + 1, tallies=True) for r in rows}
+    ref.close()
+    for threshold in (0.0, 1e30):                      # fused preparation / lists built at the first run
+        eng.set_prep_threshold(threshold)
+        for path in ("consensus", "hybrid"):
+            eng.set_path("auto")
+            eng.upload(0, codes)
+            eng.set_path(path)
+            for (m, r), w in want.items():
+                assert np.array_equal(eng.run_square(m, r, r + 1), w, equal_nan=True), (threshold, path, m, r)
+            for r, w in want_t.items():
+                assert np.array_equal(eng.run_square("tn93", r, r + 1, tallies=True), w), (threshold, path, r)
+    eng.set_prep_threshold(2e10)
+    eng.set_path("auto")
