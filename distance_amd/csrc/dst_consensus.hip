@@ -825,12 +825,24 @@ __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict_
     if (r >= n)
         return;
     uint32_t acc[kMaxWords] = {0, 0, 0, 0};
-    for (uint32_t i = off[r] + lane; i < off[r + 1]; i += 64) {
-        const uint32_t e = ent[i];
-        const uint32_t *a = lut->a[family][wide][(e >> kSiteBits) & 7u][e >> kEntryShift];
+    // four entries per lane and step, their loads issued together: a record that is mostly N has a list of thousands
+    // of entries, and one entry per step made it a chain of that many / 64 memory latencies for the whole launch
+    constexpr uint32_t UNR = 4;
+    const uint32_t end = off[r + 1];
+    for (uint32_t i = off[r] + lane; i < end; i += 64 * UNR) {
+        uint32_t e[UNR];
 #pragma unroll
-        for (int w = 0; w < kMaxWords; ++w)
-            acc[w] += a[w];
+        for (uint32_t u = 0; u < UNR; ++u)
+            e[u] = i + 64 * u < end ? ent[i + 64 * u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; ++u) {
+            if (e[u] == 0xFFFFFFFFu)
+                continue;
+            const uint32_t *a = lut->a[family][wide][(e[u] >> kSiteBits) & 7u][e[u] >> kEntryShift];
+#pragma unroll
+            for (int w = 0; w < kMaxWords; ++w)
+                acc[w] += a[w];
+        }
     }
 #pragma unroll
     for (int w = 0; w < kMaxWords; ++w) {
