@@ -16,10 +16,14 @@
 //
 //   ref_sample_kernel   per-site plurality code over a sample of records -> the reference c (from the planes, or
 //                       from the byte matrix BEFORE the pack, which then counts the list lengths on its way)
-//   index_kernel        per record: ascending list of (site, nibble) where it differs from c
+//   index_kernel        per record: ascending list of (site, nibble) where it differs from c (from the planes)
+//   slot_fill_kernel    the same lists from the 16-byte slots the pack left per (record, chunk); both mark where a list
+//                       crosses every 1,024th site (range_start), and chunks with many differences (runs of N) are
+//                       written by a whole wave (emit_chunk_by_wave)
+//   sum2 / report       list totals; what the host reads after an upload, written into page-locked memory
 //   scan kernels        exclusive scan of the list lengths -> CSR offsets
 //   site_bucket_kernel  the same entries by (panel of 2,048 column records, site): 32-byte lookup-table entries that
-//                       hold the bucket itself, assembled per (panel, 1,024 sites) in LDS from the lists
+//                       hold the bucket itself, assembled per (panel, 1,024 sites) in LDS from the lists' pieces
 //   aconst_kernel       A_k(record), packed like the accumulators
 //   consensus_pair_kernel  one block = a few rows x one column panel: the rows' lists are joined with the
 //                       site buckets of the panel, h_k goes into LDS accumulators (ds_add_u32), then one
@@ -803,13 +807,6 @@ __global__ __launch_bounds__(64) void report_kernel(const unsigned long long *__
         report[t] = stats ? stats[t - 1] : 0ull;
     else if (t < (uint32_t)kReportWords)
         report[t] = totals ? totals[t - 9] : 0ull;
-}
-
-__global__ __launch_bounds__(256) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
-        dst[i] += src[i];
 }
 
 // =============================================================================================
@@ -1652,13 +1649,6 @@ hipError_t launch_report(const unsigned long long *first_bad, const unsigned lon
                          unsigned long long *report, hipStream_t stream)
 {
     hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, first_bad, stats, totals, report);
-    return hipGetLastError();
-}
-
-hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream)
-{
-    if (n)
-        hipLaunchKernelGGL(add_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

@@ -222,7 +222,6 @@ size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0 = nullptr,
                                  const uint32_t *src1 = nullptr);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
-hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream);   // dst[i] += src[i]
 constexpr int kReportWords = 11;   // [0] first invalid byte, [1..8] the sample's statistics, [9..10] list totals
 hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const unsigned long long *totals,
                          unsigned long long *report, hipStream_t stream);
