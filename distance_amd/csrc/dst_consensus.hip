@@ -35,6 +35,10 @@
 // alignment is shorter than 65,536 sites (the sums are exact modulo 2^32 and every final tally fits).
 #include "dst_device.hpp"
 
+#ifndef DST_OVF_DEPTH
+#define DST_OVF_DEPTH 2   // measured 1 / 2 / 4 / 8 / 16: 21.1 / 17.7 / 17.3 / 24.2 / 25.6 ms on the N-heavy case of tools/nrun_bench.py
+#endif
+
 namespace dst {
 namespace {
 
@@ -1191,14 +1195,29 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 meta = __shfl(t.meta, (int)lo);
                 c = i < total ? site_ent[s_o0 + (i - s_start)] : 0u;
             };
-            uint32_t c_nx = 0, m_nx = 0;
-            fetch(0, c_nx, m_nx);
-            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
-                const uint32_t c = c_nx, meta = m_nx;
-                if (i0 + 64 < total)
-                    fetch(i0 + 64, c_nx, m_nx);
-                if (i0 + lane < total)
-                    apply(c & (kPanelCols - 1u), c >> kEntryShift, meta);
+            // kOvf x 64 entries per round, the next round's loads issued before this round's events are applied
+            // (event-heavy launches live in this loop; deeper than 2 costs more in registers and idle searches than it hides)
+            constexpr uint32_t kOvf = DST_OVF_DEPTH;
+            uint32_t c_nx[kOvf], m_nx[kOvf];
+#pragma unroll
+            for (uint32_t u = 0; u < kOvf; ++u)
+                fetch(64 * u, c_nx[u], m_nx[u]);
+            for (uint32_t i0 = 0; i0 < total; i0 += 64 * kOvf) {
+                uint32_t c[kOvf], meta[kOvf];
+#pragma unroll
+                for (uint32_t u = 0; u < kOvf; ++u) {
+                    c[u] = c_nx[u];
+                    meta[u] = m_nx[u];
+                }
+                if (i0 + 64 * kOvf < total) {
+#pragma unroll
+                    for (uint32_t u = 0; u < kOvf; ++u)
+                        fetch(i0 + 64 * (kOvf + u), c_nx[u], m_nx[u]);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kOvf; ++u)
+                    if (i0 + 64 * u + lane < total)
+                        apply(c[u] & (kPanelCols - 1u), c[u] >> kEntryShift, meta[u]);
             }
         }
     };
@@ -1228,10 +1247,25 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
             if (step < nbatch && do_events) {
                 // ---- B of batch `step` into buffer step & 1
                 apply_bucket(in_cur, step);
-                // entries beyond the 256 the pipeline carries (long lists): plain slices
+                // entries beyond the ones the pipeline carries (long lists: diverse data, records with runs of N): slice by
+                // slice, the next slice's table entries and the list entries of the one after it loaded before this slice's
+                // events are applied (one after the other every slice was two memory latencies with nothing else going on)
                 const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
-                for (uint32_t first = kEventLanes; first < run; first += kEventLanes)
-                    apply_bucket(load_inl(load_entry(step, first)), step);
+                if (run > kEventLanes) {
+#ifdef DST_DBG_PLAIN_SLICES
+                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes)
+                        apply_bucket(load_inl(load_entry(step, first)), step);
+#else
+                    Inl s_cur = load_inl(load_entry(step, kEventLanes));
+                    Entry s_en = load_entry(step, 2 * kEventLanes);
+                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes) {
+                        const Inl s_nx = load_inl(s_en);
+                        s_en = load_entry(step, first + 2 * kEventLanes);
+                        apply_bucket(s_cur, step);
+                        s_cur = s_nx;
+                    }
+#endif
+                }
                 // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
                 // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
                 // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the

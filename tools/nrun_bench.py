@@ -22,6 +22,7 @@ ap.add_argument("--measure", default="raw")
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--cases", default="0:0,0.01:0.2,0.05:0.2,0.01:0.9,0.05:0.5,0.2:0.1",
                 help="share of records : fraction of the record's sites that are N (in 1-3 runs)")
+ap.add_argument("--paths", default="auto,dense", help="auto,dense (bits compared) or auto alone (profiling)")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -46,7 +47,7 @@ for case in args.cases.split(","):
             host[r, a:a + w] = 0xF0
     codes = torch.from_numpy(host).to(dev)
     res = {}
-    for path in ("auto", "dense"):
+    for path in args.paths.split(","):
         eng.set_path(path)
         step, kern = [], []
         for rep in range(args.reps + 1):
@@ -60,7 +61,7 @@ for case in args.cases.split(","):
                 kern.append(eng.last_kernel_ms()["pair_ms"])
         bits = int(out.view(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF
         res[path] = (np.median(step), np.median(kern), eng.last_path(), bits)
-    a, d = res["auto"], res["dense"]
+    a, d = res["auto"], res.get("dense", res["auto"])
     print(f"{share:5.2f} : {frac:4.2f}   auto -> {a[2]:9s} step {a[0]:8.3f} ms (pair kernel {a[1]:8.3f})   dense step {d[0]:8.3f} ms"
           f"   bits {'equal' if a[3] == d[3] else 'DIFFER'} {a[3]:016x}")
     del codes
