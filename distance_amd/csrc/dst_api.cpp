@@ -778,7 +778,7 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             const uint64_t *st = cols.ref.h_stats;
             const double S = (double)std::max<uint64_t>(st[3], 1);
             const double events = (double)(hybrid ? st[7] : st[2]) / (S * S), list = (double)(hybrid ? st[6] : st[1]) / S;
-            cl.heavy_events = events > 0.5 || list > 100.0;
+            cl.heavy_events = events > 1.0 ? 2 : events > 0.5 || list > 100.0 ? 1 : 0;
         }
         ctx->last_path = path;
         if (ntiles) {

@@ -937,7 +937,7 @@ constexpr int event_waves()
 #endif
 }
 // 32-bit words of dynamic LDS before the logarithm table: accumulators, h table, row offsets, (ALIGNED) A(column)
-template <int FAM, bool WIDE, int OUT>
+template <int FAM, bool WIDE, int OUT, int EW>
 constexpr size_t cpair_smem_words()
 {
     constexpr int W = Pack<FAM, WIDE>::W;
@@ -946,11 +946,22 @@ constexpr size_t cpair_smem_words()
 #else
     constexpr int RBL = kAccRows;
 #endif
-    size_t words = (size_t)2 * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
+    size_t words = (size_t)(EW == kBlockWaves ? 1 : 2) * RBL * W * kPanelCols + (size_t)kRefClasses * 256 * W + kTileRowsMax + 1 +
                    (aligned_output<FAM, WIDE, OUT>() ? kPanelCols : 0);
     return (words + 3) & ~(size_t)3;   // the table's entries are 16 bytes
 }
-constexpr int kEventWavesHeavy = 4;   // launches with many events per pair or long lists (ConsensusLaunch::heavy_events)
+// Launches with many events per pair or long lists (ConsensusLaunch::heavy_events == 1): 4 event + 4 output waves.
+constexpr int kEventWavesHeavy = 4;
+// More than one event per pair (heavy_events == 2): such launches are bound by the event side's chains of dependent
+// loads, and what hides those is waves.  EW == kBlockWaves is the variant for them: no roles — all 8 waves apply a
+// batch's events, then all 8 write it out — so one accumulator buffer is enough (29 KB of LDS instead of 45 for raw:
+// more blocks per CU) and every wave of every block is an event wave (20,000 x 30,000 with 5 % of the records half N:
+// 17.6 -> 12.9 ms; below one event per pair the lost overlap of the two sides costs more than it gives).
+#ifdef DST_DBG_HEAVY_EW
+constexpr int kEventWavesAll = DST_DBG_HEAVY_EW;
+#else
+constexpr int kEventWavesAll = kBlockWaves;
+#endif
 
 // the value must be in its register HERE (an empty asm the compiler cannot move a definition across)
 __device__ __forceinline__ void pin(uint32_t &v) { asm volatile("" : "+v"(v)); }
@@ -1024,14 +1035,16 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
 #else
     constexpr int RB = kAccRows;
 #endif
-    constexpr int NOW = kBlockWaves - EW;              // EW event waves, NOW output waves
+    constexpr bool UNI = EW == kBlockWaves;            // every wave in both roles, one after the other (event-heavy launches)
+    constexpr int NOW = UNI ? kBlockWaves : kBlockWaves - EW;   // EW event waves, NOW output waves
     constexpr uint32_t kEventLanes = 64 * EW;          // entries of a batch the register pipeline carries
     constexpr uint32_t OT = 64 * NOW;                  // output threads
     constexpr int PAIRS = (kPanelCols + 2 * OT - 1) / (2 * OT);   // column pairs per output thread (panel-relative mapping)
     constexpr uint32_t ACC = RB * W * kPanelCols;  // words of one accumulator buffer
     extern __shared__ uint32_t smem[];
-    uint32_t *acc = smem;                                  // [2][RB][W][kPanelCols]
-    uint32_t *hlut = smem + 2 * ACC;                       // [kRefClasses][16][16][W]: h_k of this family
+    uint32_t *acc = smem;                                  // [2 (UNI: 1)][RB][W][kPanelCols]
+    constexpr uint32_t NBUF = UNI ? 1 : 2;
+    uint32_t *hlut = smem + NBUF * ACC;                    // [kRefClasses][16][16][W]: h_k of this family
     uint32_t *rofs = hlut + kRefClasses * 256 * W;         // [kTileRowsMax + 1] list offsets of the tile's rows
     // Single-word families (n, n_high, raw, jc69 below 65,536 sites) are bound by WRITING the results, and the
     // write rate depends on the store pattern (tools/ubench/store_rate.hip on MI355X, 10 GB triangle: every output
@@ -1044,16 +1057,16 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     // the logarithm's table (2 KB) in LDS for the measures that take one: an output wave must not load from global
     // memory between its result stores (one in-order counter for loads and stores: the load waits for every earlier store)
     constexpr bool LOGS = OUT == DST_JC69 || OUT == DST_K80 || OUT == DST_TN93;
-    LogEntry *logtab = reinterpret_cast<LogEntry *>(smem + cpair_smem_words<FAM, WIDE, OUT>());
+    LogEntry *logtab = reinterpret_cast<LogEntry *>(smem + cpair_smem_words<FAM, WIDE, OUT, EW>());
 
     const ConsensusTile tile = tiles[blockIdx.x];
     const uint32_t panel0 = tile.panel * kPanelCols;
     const uint32_t pcols = min(kPanelCols, n_cols - panel0);
-    const bool event_role = threadIdx.x >= OT;
+    const bool event_role = !UNI && threadIdx.x >= OT;
     const uint32_t tid = event_role ? threadIdx.x - OT : threadIdx.x, lane = threadIdx.x & 63u;   // index within the role
     const uint32_t trows = tile.i1 - tile.i0;              // <= kTileRowsMax
     const uint32_t nbatch = (trows + RB - 1) / RB;
-    for (uint32_t k = threadIdx.x; k < 2 * ACC; k += blockDim.x)
+    for (uint32_t k = threadIdx.x; k < NBUF * ACC; k += blockDim.x)
         acc[k] = 0;
     for (uint32_t k = threadIdx.x; k < kRefClasses * 256 * W; k += blockDim.x)
         hlut[k] = (&lut->h[FAM][WIDE ? 1 : 0][0][0][0][0])[(k / W) * kMaxWords + k % W];
@@ -1142,7 +1155,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     // bucket holds beyond them comes from the bucket array, shared out over the wave
     auto apply_bucket = [&](const Inl &t, uint32_t b) {
         const uint32_t q0 = tile.i0 + b * RB;
-        uint32_t *bacc = acc + (b & 1u) * ACC;
+        uint32_t *bacc = acc + (UNI ? 0u : b & 1u) * ACC;
         // one candidate event: column record + nibble from the bucket, h_k from the table, into the accumulators.
         // meta = row of the batch << 8 | (reference class << 4 | row nibble): the table row and the accumulator
         // row are per-entry values; per event there is the column's nibble and its place in the panel.
@@ -1221,72 +1234,9 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
             }
         }
     };
-    // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory: hipcc puts
-    // s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all their result
-    // stores have landed in HBM and the event waves wait for the loads they have just issued for the coming batches.
-    // Nothing in global memory is handed between the waves of this kernel, so only the LDS traffic (lgkmcnt) has to be
-    // complete.  The two roles run SEPARATE loops with the same number of barriers (s_barrier counts arrivals, it
-    // does not care where a wave stands): the event pipeline's registers are then not live in the output code and
-    // the other way round — the kernel needs the larger of the two register sets, not their sum.
-#define DST_BATCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    if (event_role) {
-        const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u};
-        Entry en_n2{0u, 0u, false};
-        Inl in_cur = inl_none, in_nx = inl_none;
-#ifdef DST_DBG_NO_EVENTS
-        const bool do_events = false;
-#else
-        const bool do_events = true;
-#endif
-        if (do_events) {  // prologue: batch 0's and batch 1's table entries, batch 2's list entry
-            in_cur = load_inl(load_entry(0, 0));
-            in_nx = load_inl(load_entry(1, 0));
-            en_n2 = load_entry(2, 0);
-        }
-        for (uint32_t step = 0; step <= nbatch; ++step) {
-            if (step < nbatch && do_events) {
-                // ---- B of batch `step` into buffer step & 1
-                apply_bucket(in_cur, step);
-                // entries beyond the ones the pipeline carries (long lists: diverse data, records with runs of N): slice by
-                // slice, the next slice's table entries and the list entries of the one after it loaded before this slice's
-                // events are applied (one after the other every slice was two memory latencies with nothing else going on)
-                const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
-                if (run > kEventLanes) {
-#ifdef DST_DBG_PLAIN_SLICES
-                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes)
-                        apply_bucket(load_inl(load_entry(step, first)), step);
-#else
-                    Inl s_cur = load_inl(load_entry(step, kEventLanes));
-                    Entry s_en = load_entry(step, 2 * kEventLanes);
-                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes) {
-                        const Inl s_nx = load_inl(s_en);
-                        s_en = load_entry(step, first + 2 * kEventLanes);
-                        apply_bucket(s_cur, step);
-                        s_cur = s_nx;
-                    }
-#endif
-                }
-                // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
-                // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
-                // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
-                // loads it has just issued: no overlap at all.  pin() fixes the copies in place, the scheduling
-                // barrier keeps the loads below them.
-                in_cur = in_nx;
-                Entry en_use = en_n2;
-                pin(in_cur.lo.x), pin(in_cur.lo.y), pin(in_cur.lo.z), pin(in_cur.lo.w);
-                pin(in_cur.hi.x), pin(in_cur.hi.y), pin(in_cur.hi.z), pin(in_cur.hi.w);
-                pin(in_cur.meta), pin(en_use.e), pin(en_use.rb);
-                __builtin_amdgcn_sched_barrier(0);
-                in_nx = load_inl(en_use);
-                en_n2 = load_entry(step + 3, 0);
-            }
-            DST_BATCH_BARRIER();
-        }
-    } else {
-        for (uint32_t step = 0; step <= nbatch; ++step) {
-            if (step >= 1) {
-            // ---- C of batch step - 1 from buffer (step - 1) & 1: constants, finalisation, canonical-order store
-            const uint32_t b = step - 1, q0 = tile.i0 + b * RB;
+    // ---- C of batch b from its accumulator buffer: constants, finalisation, canonical-order store
+    auto output_batch = [&](const uint32_t b) {
+            const uint32_t q0 = tile.i0 + b * RB;
             const uint32_t nrows = min((uint32_t)RB, tile.i1 - q0);
             for (uint32_t rb = 0; rb < nrows; ++rb) {
                 const uint32_t q = q0 + rb;
@@ -1299,7 +1249,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     qc = reinterpret_cast<const uint4 *>(q_counts)[q];
                 const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
                                                : (uint64_t)(q - row_begin) * n_cols;
-                uint32_t *racc = acc + (b & 1u) * ACC + rb * W * kPanelCols;
+                uint32_t *racc = acc + (UNI ? 0u : b & 1u) * ACC + rb * W * kPanelCols;
                 // two adjacent results of row q: columns panel0 + ks and panel0 + ks + 1 (ks may be -1 .. pcols - 1:
                 // ALIGNED pairs straddle the panel's edges); j: the thread's register copy of A(column) (HOIST)
                 // cav / tcv: the hoisted A(column) words and packed base counts of the two columns (nullptr when ALIGNED)
@@ -1520,7 +1470,91 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                         do_slot(j, ca[j], tcp[0]);
                 }
             }
+    };
+    // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory: hipcc puts
+    // s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all their result
+    // stores have landed in HBM and the event waves wait for the loads they have just issued for the coming batches.
+    // Nothing in global memory is handed between the waves of this kernel, so only the LDS traffic (lgkmcnt) has to be
+    // complete.  The two roles run SEPARATE loops with the same number of barriers (s_barrier counts arrivals, it
+    // does not care where a wave stands): the event pipeline's registers are then not live in the output code and
+    // the other way round — the kernel needs the larger of the two register sets, not their sum.
+#define DST_BATCH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if constexpr (UNI) {
+        for (uint32_t b = 0; b < nbatch; ++b) {
+            // the batch's entries kEventLanes at a time, the next slice's table entries and the list entries of the one
+            // after it loaded before this slice's events are applied
+            const uint32_t run = rofs[min(b * RB + RB, trows)] - rofs[b * RB];
+            if (run) {
+                Inl s_cur = load_inl(load_entry(b, 0));
+                Entry s_en = load_entry(b, kEventLanes);
+                for (uint32_t first = 0; first < run; first += kEventLanes) {
+                    const Inl s_nx = load_inl(s_en);
+                    s_en = load_entry(b, first + 2 * kEventLanes);
+                    apply_bucket(s_cur, b);
+                    s_cur = s_nx;
+                }
+            }
+            DST_BATCH_BARRIER();
+            output_batch(b);
+            DST_BATCH_BARRIER();
         }
+    } else if (event_role) {
+        const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u};
+        Entry en_n2{0u, 0u, false};
+        Inl in_cur = inl_none, in_nx = inl_none;
+#ifdef DST_DBG_NO_EVENTS
+        const bool do_events = false;
+#else
+        const bool do_events = true;
+#endif
+        if (do_events) {  // prologue: batch 0's and batch 1's table entries, batch 2's list entry
+            in_cur = load_inl(load_entry(0, 0));
+            in_nx = load_inl(load_entry(1, 0));
+            en_n2 = load_entry(2, 0);
+        }
+        for (uint32_t step = 0; step <= nbatch; ++step) {
+            if (step < nbatch && do_events) {
+                // ---- B of batch `step` into buffer step & 1
+                apply_bucket(in_cur, step);
+                // entries beyond the ones the pipeline carries (long lists: diverse data, records with runs of N): slice by
+                // slice, the next slice's table entries and the list entries of the one after it loaded before this slice's
+                // events are applied (one after the other every slice was two memory latencies with nothing else going on)
+                const uint32_t run = rofs[min(step * RB + RB, trows)] - rofs[step * RB];
+                if (run > kEventLanes) {
+#ifdef DST_DBG_PLAIN_SLICES
+                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes)
+                        apply_bucket(load_inl(load_entry(step, first)), step);
+#else
+                    Inl s_cur = load_inl(load_entry(step, kEventLanes));
+                    Entry s_en = load_entry(step, 2 * kEventLanes);
+                    for (uint32_t first = kEventLanes; first < run; first += kEventLanes) {
+                        const Inl s_nx = load_inl(s_en);
+                        s_en = load_entry(step, first + 2 * kEventLanes);
+                        apply_bucket(s_cur, step);
+                        s_cur = s_nx;
+                    }
+#endif
+                }
+                // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
+                // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
+                // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
+                // loads it has just issued: no overlap at all.  pin() fixes the copies in place, the scheduling
+                // barrier keeps the loads below them.
+                in_cur = in_nx;
+                Entry en_use = en_n2;
+                pin(in_cur.lo.x), pin(in_cur.lo.y), pin(in_cur.lo.z), pin(in_cur.lo.w);
+                pin(in_cur.hi.x), pin(in_cur.hi.y), pin(in_cur.hi.z), pin(in_cur.hi.w);
+                pin(in_cur.meta), pin(en_use.e), pin(en_use.rb);
+                __builtin_amdgcn_sched_barrier(0);
+                in_nx = load_inl(en_use);
+                en_n2 = load_entry(step + 3, 0);
+            }
+            DST_BATCH_BARRIER();
+        }
+    } else {
+        for (uint32_t step = 0; step <= nbatch; ++step) {
+            if (step >= 1)
+                output_batch(step - 1);
             DST_BATCH_BARRIER();
         }
     }
@@ -1699,7 +1733,7 @@ namespace {
 template <int FAM, bool WIDE, int OUT, int EW>
 hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
-    const size_t smem = cpair_smem_words<FAM, WIDE, OUT>() * sizeof(uint32_t) +
+    const size_t smem = cpair_smem_words<FAM, WIDE, OUT, EW>() * sizeof(uint32_t) +
                         (OUT == DST_JC69 || OUT == DST_K80 || OUT == DST_TN93 ? 128 * sizeof(LogEntry) : 0);
     auto kern = consensus_pair_kernel<FAM, WIDE, OUT, EW>;
     if (smem > 64 * 1024) {
@@ -1719,6 +1753,8 @@ hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStrea
 template <int FAM, bool WIDE, int OUT>
 hipError_t launch_cpair(const ConsensusLaunch &cl, const FWords &fw, hipStream_t stream)
 {
+    if (cl.heavy_events >= 2)
+        return launch_cpair_ew<FAM, WIDE, OUT, kEventWavesAll>(cl, fw, stream);
     if (cl.heavy_events)
         return launch_cpair_ew<FAM, WIDE, OUT, kEventWavesHeavy>(cl, fw, stream);
     return launch_cpair_ew<FAM, WIDE, OUT, event_waves<FAM, WIDE, OUT>()>(cl, fw, stream);

@@ -195,7 +195,8 @@ struct ConsensusLaunch {
     bool wide;                   // one 32-bit word per tally (alignments of 65,536 sites or more)
     const ConsensusLut *d_lut;
     const void *d_hot = nullptr; // hybrid path: the dense kernels' tallies of the hot columns (TALLY16 / TALLY layout)
-    bool heavy_events = false;   // many events per pair or long lists: more of the workgroup's waves take the event role
+    int heavy_events = 0;        // 1: many events per pair or long lists — more of the workgroup's waves take the event role;
+                                 // 2: more than one event per pair — every wave in both roles (consensus_pair_kernel)
 };
 
 // ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
