@@ -569,7 +569,7 @@ int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uin
     //                                            n       n_high  raw      jc69     k80      tn93
     static const double dense_site_pairs_per_s[6] = {2.9e14, 2.9e14, 1.95e14, 1.92e14, 1.82e14, 1.48e14};
     static const double out_s_per_pair[6] = {2.2e-12, 2.2e-12, 2.3e-12, 3.9e-12, 5.0e-12, 1.55e-11};
-    constexpr double event_s = 2.0e-12;   // per event, launches of more than one per pair (1.8-2.3 ps measured; 4.5 before the
+    constexpr double event_s = 1.85e-12;  // per event, launches of more than one per pair (1.8-2.3 ps measured; 4.5 before the
                                           // all-waves launch variant)
     const uint64_t *st = cols.ref.h_stats;
     const double S = (double)std::max<uint64_t>(st[3], 1);

@@ -60,7 +60,7 @@ constexpr uint32_t kRefSamples = 512;      // records sampled for the reference 
 constexpr int kRefClasses = 5;             // reference nibbles: A(8) G(4) C(2) T(1) N-class(15)
 constexpr int kMaxWords = 4;               // packed accumulator words per pair
 constexpr uint32_t kHotPermille = 50;      // hybrid path: a site is "hot" when more than 5 % of the sampled records deviate
-                                           // (p^2 x 2.0 ps per event against 1 / 1.95e14 s per dense site and pair; 33 while an event cost 4.5 ps)
+                                           // (p^2 x 1.85 ps per event against 1 / 1.95e14 s per dense site and pair; 33 while an event cost 4.5 ps)
 
 struct ConsensusRef {             // the reference sequence, sampled from the set that owns it
     uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records'); N past len
