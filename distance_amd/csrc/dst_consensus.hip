@@ -935,8 +935,9 @@ constexpr int event_waves()
 #else
     // tn93 is bound by the f64 finalisation, and a wave that only gathers events leaves its SIMD with one finalising wave
     // where the others have two: all 8 waves in both roles instead (kBlockWaves: no event role at all) — 15.0 -> 13.5 ms
-    // at 50,000 x 30,000; k80 gains 1 % that way and jc69 loses 9 %, they keep their roles
-    return OUT == DST_TN93 && !WIDE ? kBlockWaves : OUT == DST_TN93 || OUT == DST_K80 ? 1 : 2;
+    // at 50,000 x 30,000; k80 gains 1 % that way and jc69 loses 9 %, they keep their roles (k80 with two event waves:
+    // with one, 5.16 ms, the batch's ~130 entries took three slices and the seven output waves waited for them: 4.61)
+    return OUT == DST_TN93 ? (WIDE ? 1 : kBlockWaves) : 2;
 #endif
 }
 // 32-bit words of dynamic LDS before the logarithm table: accumulators, h table, row offsets, (ALIGNED) A(column)
