@@ -1240,240 +1240,240 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     };
     // ---- C of batch b from its accumulator buffer: constants, finalisation, canonical-order store
     auto output_batch = [&](const uint32_t b) {
-            const uint32_t q0 = tile.i0 + b * RB;
-            const uint32_t nrows = min((uint32_t)RB, tile.i1 - q0);
-            for (uint32_t rb = 0; rb < nrows; ++rb) {
-                const uint32_t q = q0 + rb;
-                uint32_t aq[W];
+        const uint32_t q0 = tile.i0 + b * RB;
+        const uint32_t nrows = min((uint32_t)RB, tile.i1 - q0);
+        for (uint32_t rb = 0; rb < nrows; ++rb) {
+            const uint32_t q = q0 + rb;
+            uint32_t aq[W];
 #pragma unroll
-                for (int w = 0; w < W; ++w)
-                    aq[w] = row_a[(size_t)w * row_npad + q] + fw.w[w];
-                uint4 qc = make_uint4(0, 0, 0, 0);
-                if constexpr (OUT == DST_TN93)
-                    qc = reinterpret_cast<const uint4 *>(q_counts)[q];
-                const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
-                                               : (uint64_t)(q - row_begin) * n_cols;
-                uint32_t *racc = acc + (UNI ? 0u : b & 1u) * ACC + rb * W * kPanelCols;
-                // two adjacent results of row q: columns panel0 + ks and panel0 + ks + 1 (ks may be -1 .. pcols - 1:
-                // ALIGNED pairs straddle the panel's edges); j: the thread's register copy of A(column) (HOIST)
-                // cav / tcv: the hoisted A(column) words and packed base counts of the two columns (nullptr when ALIGNED)
-                auto do_pair = [&](int32_t ks, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
-                    bool in[2], live[2];
+            for (int w = 0; w < W; ++w)
+                aq[w] = row_a[(size_t)w * row_npad + q] + fw.w[w];
+            uint4 qc = make_uint4(0, 0, 0, 0);
+            if constexpr (OUT == DST_TN93)
+                qc = reinterpret_cast<const uint4 *>(q_counts)[q];
+            const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
+                                           : (uint64_t)(q - row_begin) * n_cols;
+            uint32_t *racc = acc + (UNI ? 0u : b & 1u) * ACC + rb * W * kPanelCols;
+            // two adjacent results of row q: columns panel0 + ks and panel0 + ks + 1 (ks may be -1 .. pcols - 1:
+            // ALIGNED pairs straddle the panel's edges); j: the thread's register copy of A(column) (HOIST)
+            // cav / tcv: the hoisted A(column) words and packed base counts of the two columns (nullptr when ALIGNED)
+            auto do_pair = [&](int32_t ks, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
+                bool in[2], live[2];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        in[h] = (uint32_t)(ks + h) < pcols;
-                        live[h] = in[h] && (!square || panel0 + (uint32_t)(ks + h) > q);
-                    }
-                    if (!live[1] && !live[0])
-                        return;  // outside the panel, or square: at or below the diagonal (accumulators stay 0 there)
-                    const uint64_t at = row_at + panel0 + (uint64_t)(int64_t)ks;   // modulo 2^64: right wherever live
-                    uint32_t o[2][NT];
+                for (int h = 0; h < 2; ++h) {
+                    in[h] = (uint32_t)(ks + h) < pcols;
+                    live[h] = in[h] && (!square || panel0 + (uint32_t)(ks + h) > q);
+                }
+                if (!live[1] && !live[0])
+                    return;  // outside the panel, or square: at or below the diagonal (accumulators stay 0 there)
+                const uint64_t at = row_at + panel0 + (uint64_t)(int64_t)ks;   // modulo 2^64: right wherever live
+                uint32_t o[2][NT];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t k = in[h] ? (uint32_t)(ks + h) : 0u;
-                        uint32_t tot[W];
-#pragma unroll
-                        for (int w = 0; w < W; ++w) {
-                            const uint32_t a = racc[w * kPanelCols + k];
-                            if (a && in[h])
-                                racc[w * kPanelCols + k] = 0;
-                            uint32_t cav;
-                            if constexpr (ALIGNED)
-                                cav = cola[k];
-                            else
-                                cav = cav2[h][w];
-                            tot[w] = a + cav + aq[w];
-                        }
-                        if (hot && live[h])
-                            P::add_hot(tot, hot, at + h);   // hybrid path: the dense kernels' tallies of the hot columns
-                        P::unpack(tot, o[h]);
-                    }
-                    if constexpr (OUT == OUT_INT) {
-                        int64_t *out = static_cast<int64_t *>(out_v);
-#ifdef DST_DBG_NO_STORE
-                        if (o[0][0] != 0xFFFFFFF0u)
-                            return;
-#endif
-                        if (live[0] && live[1]) {
-                            store_result2(out + at, (int64_t)o[0][0], (int64_t)o[1][0]);
-                        } else if (live[0]) {
-                            store_result(out + at, (int64_t)o[0][0]);
-                        } else {
-                            store_result(out + at + 1, (int64_t)o[1][0]);
-                        }
-                    } else if constexpr (OUT == OUT_TALLY) {
-                        uint32_t *out = static_cast<uint32_t *>(out_v);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            if (live[h])
-#pragma unroll
-                                for (int x = 0; x < NT; ++x)
-                                    store_result(out + (at + h) * NT + x, o[h][x]);
-                    } else if constexpr (OUT == OUT_TALLY16) {
-                        uint16_t *out = static_cast<uint16_t *>(out_v);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            if (live[h])
-#pragma unroll
-                                for (int x = 0; x < NT; ++x)
-                                    store_result(out + (at + h) * NT + x, (uint16_t)o[h][x]);
-                    } else {
-                        double *out = static_cast<double *>(out_v);
-                        double d[2] = {0.0, 0.0};
-                        auto fin = [&](int h) {
-                            if (live[h]) {
-                                uint4 tc = make_uint4(0, 0, 0, 0);
-                                if constexpr (HOIST_TC) {
-                                    if constexpr (WIDE)
-                                        tc = make_uint4(tcv[h][0], tcv[h][1], tcv[h][2], tcv[h][3]);
-                                    else
-                                        tc = make_uint4(tcv[h][0] & 0xFFFFu, tcv[h][0] >> 16, tcv[h][1] & 0xFFFFu, tcv[h][1] >> 16);
-                                } else if constexpr (OUT == DST_TN93) {
-                                    tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
-                                }
-                                d[h] = finalize_pair<OUT>(o[h], qc, tc, LOGS ? logtab : kLogTab);
-                            }
-                        };
-                        fin(0);   // (two copies of the formula: the two results' dependency chains interleave)
-                        fin(1);
-#ifdef DST_DBG_NO_STORE
-                        if (d[0] != -12345.5)
-                            return;
-#endif
-                        if (live[0] && live[1]) {
-                            store_result2(out + at, d[0], d[1]);
-                        } else if (live[0]) {
-                            store_result(out + at, d[0]);
-                        } else {
-                            store_result(out + at + 1, d[1]);
-                        }
-                    }
-                };
-                // Two adjacent results whose columns k, k + 1 are known to lie inside the panel and past the diagonal (a
-                // whole group of a wave does): none of do_pair's per-lane tests, which cost ~50 scalar instructions per
-                // pair of results (exec-mask bookkeeping) — more than the one scalar unit of a CU keeps up with at the
-                // write rate.  c0 / c1: A(column) words; t0 / t1: the columns' base counts (tn93).
-                auto fast_pair = [&](uint32_t k, const uint32_t *c0, const uint32_t *c1, uint4 tc0, uint4 tc1) {
-                    uint32_t w0[W], w1[W];
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t k = in[h] ? (uint32_t)(ks + h) : 0u;
+                    uint32_t tot[W];
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
-                        w0[w] = racc[w * kPanelCols + k] + c0[w] + aq[w];
-                        w1[w] = racc[w * kPanelCols + k + 1] + c1[w] + aq[w];
-                        racc[w * kPanelCols + k] = 0;          // (unconditional: cheaper than testing)
-                        racc[w * kPanelCols + k + 1] = 0;
+                        const uint32_t a = racc[w * kPanelCols + k];
+                        if (a && in[h])
+                            racc[w * kPanelCols + k] = 0;
+                        uint32_t cav;
+                        if constexpr (ALIGNED)
+                            cav = cola[k];
+                        else
+                            cav = cav2[h][w];
+                        tot[w] = a + cav + aq[w];
                     }
-                    uint32_t o0[NT], o1[NT];
-                    P::unpack(w0, o0);
-                    P::unpack(w1, o1);
-                    const uint64_t at = row_at + panel0 + k;
-                    if constexpr (OUT == OUT_INT) {
-                        store_result2(static_cast<int64_t *>(out_v) + at, (int64_t)o0[0], (int64_t)o1[0]);
-                    } else if constexpr (OUT == OUT_TALLY) {
-                        uint32_t *out = static_cast<uint32_t *>(out_v) + at * NT;
-#pragma unroll
-                        for (int x = 0; x < NT; ++x) {
-                            store_result(out + x, o0[x]);
-                            store_result(out + NT + x, o1[x]);
-                        }
-                    } else if constexpr (OUT == OUT_TALLY16) {
-                        uint16_t *out = static_cast<uint16_t *>(out_v) + at * NT;
-#pragma unroll
-                        for (int x = 0; x < NT; ++x) {
-                            store_result(out + x, (uint16_t)o0[x]);
-                            store_result(out + NT + x, (uint16_t)o1[x]);
-                        }
-                    } else {
-                        const double d0 = finalize_pair<OUT>(o0, qc, tc0, LOGS ? logtab : kLogTab);
-                        const double d1 = finalize_pair<OUT>(o1, qc, tc1, LOGS ? logtab : kLogTab);
-#ifdef DST_DBG_NO_STORE
-                        if (d0 != -12345.5)
-                            return;
-#endif
-                        store_result2(static_cast<double *>(out_v) + at, d0, d1);
-                    }
-                };
-                // is the wave's group of 128 columns from k0 on (uniform) wholly inside the panel and past the diagonal?
-                auto whole_group = [&](int32_t k0) {
-                    return k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) && hot == nullptr;
-                };
-                if constexpr (ALIGNED) {
-                    // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
-                    // or 17 lines-of-1-KB groups from that line's start go to the output waves as contiguous runs:
-                    // a wave's stores are whole, consecutive lines; only the panel's two edge lines are shared with
-                    // the neighbouring tiles.
-                    constexpr uint32_t ELEM = OUT == OUT_TALLY ? 4u * NT : OUT == OUT_TALLY16 ? 2u * NT : 8u;
-                    const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(out_v) / ELEM + row_at + panel0) & 15u);
-                    // 17 groups over NOW waves: BASE each, the first REM waves (in an order rotating with the row) one more
-                    constexpr uint32_t GROUPS = kPanelCols / 128 + 1, BASE = GROUPS / NOW, REM = GROUPS % NOW;
-                    const uint32_t wv = tid >> 6, idx = (wv + NOW - q % NOW) % NOW;
-                    const uint32_t g0 = idx * BASE + min(idx, REM);
-                    auto do_group = [&](uint32_t g) {
-                        const int32_t k0 = (int32_t)(128u * g) - (int32_t)sh;          // the group's first column (uniform)
-                        if (!whole_group(k0)) {
-                            do_pair(k0 + (int32_t)(2u * lane), nullptr, nullptr);
-                            return;
-                        }
-                        const uint32_t k = (uint32_t)k0 + 2u * lane;
-                        const uint4 none = make_uint4(0, 0, 0, 0);
-                        fast_pair(k, &cola[k], &cola[k + 1], none, none);
-                    };
-#pragma unroll
-                    for (uint32_t g = 0; g < BASE; ++g)
-                        do_group(g0 + g);
-                    if (idx < REM)
-                        do_group(g0 + BASE);
+                    if (hot && live[h])
+                        P::add_hot(tot, hot, at + h);   // hybrid path: the dense kernels' tallies of the hot columns
+                    P::unpack(tot, o[h]);
                 }
-                // panel-relative mapping: slot j of this wave = columns 2 (tid's wave x 64) + 2 OT j .. + 128
-                auto do_slot = [&](int j, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
-                    const int32_t k0 = (int32_t)(2u * (tid & ~63u) + 2u * OT * (uint32_t)j);
-                    if (!whole_group(k0)) {
-                        do_pair(k0 + (int32_t)(2u * lane), cav2, tcv);
+                if constexpr (OUT == OUT_INT) {
+                    int64_t *out = static_cast<int64_t *>(out_v);
+#ifdef DST_DBG_NO_STORE
+                    if (o[0][0] != 0xFFFFFFF0u)
                         return;
+#endif
+                    if (live[0] && live[1]) {
+                        store_result2(out + at, (int64_t)o[0][0], (int64_t)o[1][0]);
+                    } else if (live[0]) {
+                        store_result(out + at, (int64_t)o[0][0]);
+                    } else {
+                        store_result(out + at + 1, (int64_t)o[1][0]);
                     }
-                    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
-                    if constexpr (HOIST_TC) {
-                        if constexpr (WIDE) {
-                            t0 = make_uint4(tcv[0][0], tcv[0][1], tcv[0][2], tcv[0][3]);
-                            t1 = make_uint4(tcv[1][0], tcv[1][1], tcv[1][2], tcv[1][3]);
-                        } else {
-                            t0 = make_uint4(tcv[0][0] & 0xFFFFu, tcv[0][0] >> 16, tcv[0][1] & 0xFFFFu, tcv[0][1] >> 16);
-                            t1 = make_uint4(tcv[1][0] & 0xFFFFu, tcv[1][0] >> 16, tcv[1][1] & 0xFFFFu, tcv[1][1] >> 16);
+                } else if constexpr (OUT == OUT_TALLY) {
+                    uint32_t *out = static_cast<uint32_t *>(out_v);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (live[h])
+#pragma unroll
+                            for (int x = 0; x < NT; ++x)
+                                store_result(out + (at + h) * NT + x, o[h][x]);
+                } else if constexpr (OUT == OUT_TALLY16) {
+                    uint16_t *out = static_cast<uint16_t *>(out_v);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (live[h])
+#pragma unroll
+                            for (int x = 0; x < NT; ++x)
+                                store_result(out + (at + h) * NT + x, (uint16_t)o[h][x]);
+                } else {
+                    double *out = static_cast<double *>(out_v);
+                    double d[2] = {0.0, 0.0};
+                    auto fin = [&](int h) {
+                        if (live[h]) {
+                            uint4 tc = make_uint4(0, 0, 0, 0);
+                            if constexpr (HOIST_TC) {
+                                if constexpr (WIDE)
+                                    tc = make_uint4(tcv[h][0], tcv[h][1], tcv[h][2], tcv[h][3]);
+                                else
+                                    tc = make_uint4(tcv[h][0] & 0xFFFFu, tcv[h][0] >> 16, tcv[h][1] & 0xFFFFu, tcv[h][1] >> 16);
+                            } else if constexpr (OUT == DST_TN93) {
+                                tc = reinterpret_cast<const uint4 *>(t_counts)[panel0 + (uint32_t)(ks + h)];
+                            }
+                            d[h] = finalize_pair<OUT>(o[h], qc, tc, LOGS ? logtab : kLogTab);
                         }
+                    };
+                    fin(0);   // (two copies of the formula: the two results' dependency chains interleave)
+                    fin(1);
+#ifdef DST_DBG_NO_STORE
+                    if (d[0] != -12345.5)
+                        return;
+#endif
+                    if (live[0] && live[1]) {
+                        store_result2(out + at, d[0], d[1]);
+                    } else if (live[0]) {
+                        store_result(out + at, d[0]);
+                    } else {
+                        store_result(out + at + 1, d[1]);
                     }
-                    fast_pair((uint32_t)k0 + 2u * lane, cav2[0], cav2[1], t0, t1);
-                };
-                if constexpr (ALIGNED) {
-                } else if constexpr (OUT == DST_TN93) {
-                    // one copy of the pair's code (two of the formula), not PAIRS: tn93's registers are at the limit the
-                    // LDS leaves (128); the hoisted values of slot j are picked by selects, not by indexing
-#pragma unroll 1
-                    for (int j = 0; j < PAIRS; ++j) {
-                        uint32_t cc[2][W], tt[2][TCW];
+                }
+            };
+            // Two adjacent results whose columns k, k + 1 are known to lie inside the panel and past the diagonal (a
+            // whole group of a wave does): none of do_pair's per-lane tests, which cost ~50 scalar instructions per
+            // pair of results (exec-mask bookkeeping) — more than the one scalar unit of a CU keeps up with at the
+            // write rate.  c0 / c1: A(column) words; t0 / t1: the columns' base counts (tn93).
+            auto fast_pair = [&](uint32_t k, const uint32_t *c0, const uint32_t *c1, uint4 tc0, uint4 tc1) {
+                uint32_t w0[W], w1[W];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                for (int w = 0; w < W; ++w) {
+                    w0[w] = racc[w * kPanelCols + k] + c0[w] + aq[w];
+                    w1[w] = racc[w * kPanelCols + k + 1] + c1[w] + aq[w];
+                    racc[w * kPanelCols + k] = 0;          // (unconditional: cheaper than testing)
+                    racc[w * kPanelCols + k + 1] = 0;
+                }
+                uint32_t o0[NT], o1[NT];
+                P::unpack(w0, o0);
+                P::unpack(w1, o1);
+                const uint64_t at = row_at + panel0 + k;
+                if constexpr (OUT == OUT_INT) {
+                    store_result2(static_cast<int64_t *>(out_v) + at, (int64_t)o0[0], (int64_t)o1[0]);
+                } else if constexpr (OUT == OUT_TALLY) {
+                    uint32_t *out = static_cast<uint32_t *>(out_v) + at * NT;
 #pragma unroll
-                            for (int w = 0; w < W; ++w) {
-                                cc[h][w] = ca[0][h][w];
+                    for (int x = 0; x < NT; ++x) {
+                        store_result(out + x, o0[x]);
+                        store_result(out + NT + x, o1[x]);
+                    }
+                } else if constexpr (OUT == OUT_TALLY16) {
+                    uint16_t *out = static_cast<uint16_t *>(out_v) + at * NT;
 #pragma unroll
-                                for (int jj = 1; jj < PAIRS; ++jj)
-                                    cc[h][w] = j == jj ? ca[jj][h][w] : cc[h][w];
-                            }
-#pragma unroll
-                            for (int x = 0; x < TCW; ++x) {
-                                tt[h][x] = tcp[0][h][x];
-#pragma unroll
-                                for (int jj = 1; jj < PAIRS; ++jj)
-                                    tt[h][x] = j == jj ? tcp[jj][h][x] : tt[h][x];
-                            }
-                        }
-                        do_slot(j, cc, tt);
+                    for (int x = 0; x < NT; ++x) {
+                        store_result(out + x, (uint16_t)o0[x]);
+                        store_result(out + NT + x, (uint16_t)o1[x]);
                     }
                 } else {
-#pragma unroll
-                    for (int j = 0; j < PAIRS; ++j)
-                        do_slot(j, ca[j], tcp[0]);
+                    const double d0 = finalize_pair<OUT>(o0, qc, tc0, LOGS ? logtab : kLogTab);
+                    const double d1 = finalize_pair<OUT>(o1, qc, tc1, LOGS ? logtab : kLogTab);
+#ifdef DST_DBG_NO_STORE
+                    if (d0 != -12345.5)
+                        return;
+#endif
+                    store_result2(static_cast<double *>(out_v) + at, d0, d1);
                 }
+            };
+            // is the wave's group of 128 columns from k0 on (uniform) wholly inside the panel and past the diagonal?
+            auto whole_group = [&](int32_t k0) {
+                return k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) && hot == nullptr;
+            };
+            if constexpr (ALIGNED) {
+                // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
+                // or 17 lines-of-1-KB groups from that line's start go to the output waves as contiguous runs:
+                // a wave's stores are whole, consecutive lines; only the panel's two edge lines are shared with
+                // the neighbouring tiles.
+                constexpr uint32_t ELEM = OUT == OUT_TALLY ? 4u * NT : OUT == OUT_TALLY16 ? 2u * NT : 8u;
+                const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(out_v) / ELEM + row_at + panel0) & 15u);
+                // 17 groups over NOW waves: BASE each, the first REM waves (in an order rotating with the row) one more
+                constexpr uint32_t GROUPS = kPanelCols / 128 + 1, BASE = GROUPS / NOW, REM = GROUPS % NOW;
+                const uint32_t wv = tid >> 6, idx = (wv + NOW - q % NOW) % NOW;
+                const uint32_t g0 = idx * BASE + min(idx, REM);
+                auto do_group = [&](uint32_t g) {
+                    const int32_t k0 = (int32_t)(128u * g) - (int32_t)sh;          // the group's first column (uniform)
+                    if (!whole_group(k0)) {
+                        do_pair(k0 + (int32_t)(2u * lane), nullptr, nullptr);
+                        return;
+                    }
+                    const uint32_t k = (uint32_t)k0 + 2u * lane;
+                    const uint4 none = make_uint4(0, 0, 0, 0);
+                    fast_pair(k, &cola[k], &cola[k + 1], none, none);
+                };
+#pragma unroll
+                for (uint32_t g = 0; g < BASE; ++g)
+                    do_group(g0 + g);
+                if (idx < REM)
+                    do_group(g0 + BASE);
             }
+            // panel-relative mapping: slot j of this wave = columns 2 (tid's wave x 64) + 2 OT j .. + 128
+            auto do_slot = [&](int j, const uint32_t (*cav2)[W], const uint32_t (*tcv)[TCW]) {
+                const int32_t k0 = (int32_t)(2u * (tid & ~63u) + 2u * OT * (uint32_t)j);
+                if (!whole_group(k0)) {
+                    do_pair(k0 + (int32_t)(2u * lane), cav2, tcv);
+                    return;
+                }
+                uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
+                if constexpr (HOIST_TC) {
+                    if constexpr (WIDE) {
+                        t0 = make_uint4(tcv[0][0], tcv[0][1], tcv[0][2], tcv[0][3]);
+                        t1 = make_uint4(tcv[1][0], tcv[1][1], tcv[1][2], tcv[1][3]);
+                    } else {
+                        t0 = make_uint4(tcv[0][0] & 0xFFFFu, tcv[0][0] >> 16, tcv[0][1] & 0xFFFFu, tcv[0][1] >> 16);
+                        t1 = make_uint4(tcv[1][0] & 0xFFFFu, tcv[1][0] >> 16, tcv[1][1] & 0xFFFFu, tcv[1][1] >> 16);
+                    }
+                }
+                fast_pair((uint32_t)k0 + 2u * lane, cav2[0], cav2[1], t0, t1);
+            };
+            if constexpr (ALIGNED) {
+            } else if constexpr (OUT == DST_TN93) {
+                // one copy of the pair's code (two of the formula), not PAIRS: tn93's registers are at the limit the
+                // LDS leaves (128); the hoisted values of slot j are picked by selects, not by indexing
+#pragma unroll 1
+                for (int j = 0; j < PAIRS; ++j) {
+                    uint32_t cc[2][W], tt[2][TCW];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            cc[h][w] = ca[0][h][w];
+#pragma unroll
+                            for (int jj = 1; jj < PAIRS; ++jj)
+                                cc[h][w] = j == jj ? ca[jj][h][w] : cc[h][w];
+                        }
+#pragma unroll
+                        for (int x = 0; x < TCW; ++x) {
+                            tt[h][x] = tcp[0][h][x];
+#pragma unroll
+                            for (int jj = 1; jj < PAIRS; ++jj)
+                                tt[h][x] = j == jj ? tcp[jj][h][x] : tt[h][x];
+                        }
+                    }
+                    do_slot(j, cc, tt);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PAIRS; ++j)
+                    do_slot(j, ca[j], tcp[0]);
+            }
+        }
     };
     // Workgroup barrier for the LDS accumulators only.  __syncthreads() is also a fence for global memory: hipcc puts
     // s_waitcnt vmcnt(0) in front of it, which makes the output waves wait at every batch until all their result
