@@ -399,3 +399,29 @@ def test_every_wave_shape_of_the_fill_pass(eng, n):
                 assert np.array_equal(eng.run_square("tn93", r, r + 1, tallies=True), w), (threshold, path, r)
     eng.set_prep_threshold(2e10)
     eng.set_path("auto")
+
+
+@pytest.mark.parametrize("L", [3000, 70000])
+def test_event_heavy_launches_on_every_path(eng, L):
+    """More than one event per pair switches the pair kernel to its no-roles launch variant (all 8 waves apply a batch's
+    events, then all 8 write it out; one accumulator buffer) — also under the hybrid path, whose cold sites alone can
+    carry that many events, and with 32-bit accumulators (L >= 65,536).  Clade structure on top of 3 % private
+    substitutions: every measure and the tallies must be the dense path's bits."""
+    n = 1500 if L < 65536 else 500
+    codes = clade_alignment(n, L, 311 + L, subs=0.03)
+    ref = da.Engine(0)
+    ref.set_path("dense")
+    ref.upload(0, codes)
+    rows = (0, n // 3, n - 2)
+    want = {(m, r): ref.run_square(m, r, r + 2 if r + 2 < n else r + 1) for m in ALL for r in rows}
+    want_t = {m: ref.run_square(m, 3, 6, tallies=True) for m in ("raw", "k80", "tn93")}
+    ref.close()
+    for path in ("consensus", "hybrid"):
+        eng.set_path("auto")
+        eng.upload(0, codes)
+        eng.set_path(path)
+        for (m, r), w in want.items():
+            assert np.array_equal(eng.run_square(m, r, r + 2 if r + 2 < n else r + 1), w, equal_nan=True), (path, m, r)
+        for m, w in want_t.items():
+            assert np.array_equal(eng.run_square(m, 3, 6, tallies=True), w), (path, m)
+    eng.set_path("auto")
