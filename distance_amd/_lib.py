@@ -89,6 +89,7 @@ _SIGS = {
     "dst_format_distance": (C.c_int, [C.c_int, C.c_double, C.c_int64, C.c_char_p, C.c_size_t]),
     "dst_set_prep_threshold": (C.c_int, [_vp, C.c_double]),
     "dst_set_ids": (C.c_int, [_vp, C.c_int, C.c_char_p, _u64p, C.c_uint64]),
+    "dst_text_stats": (C.c_int, [_vp, _u64p, _u64p]),
     "dst_text_square": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dst_text_rect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _vp, C.c_size_t,
                                 C.POINTER(C.c_size_t)]),

@@ -1143,7 +1143,10 @@ int main(int argc, char **argv)
         job.col_counts = measure == DST_TN93 ? counts.back().data() : nullptr;
         // The TSV lines themselves come from the GPU (dst_text_*): it has the distances and the ids, the exact
         // {:.12} conversion is integer arithmetic, and the host's formatter pool was what bounded a large run.
-        // DISTANCE_HOST_FORMAT=1 keeps the host formatter (the two give the same bytes: tests/test_gpu_cli.py).
+        // For jc69 / k80 / tn93 the device finalises the tallies itself and hands the values that lie near a rounding
+        // boundary of the 12th decimal back to dst_finalize (libm) before the text leaves the library, so the bytes are
+        // the host formatter's (tests/test_gpu_text_identity.py: 0 of 1.5e8 lines differ; DISTANCE_HOST_FORMAT=1 keeps
+        // the host formatter, and tests/test_gpu_cli.py compares the two).
         job.gpu_text = std::getenv("DISTANCE_HOST_FORMAT") == nullptr;
         if (job.gpu_text)
             for (int g = 0; g < G && job.gpu_text; ++g)

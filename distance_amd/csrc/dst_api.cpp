@@ -993,12 +993,14 @@ int dst_destroy(dst_ctx *ctx)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
     for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, ctx->host_out, ctx->hot_tally, ctx->text_res,
-                    ctx->text_num, (void *)ctx->text_len, (void *)ctx->text_scan, (void *)ctx->text_buf, (void *)ctx->text_flag,
+                    ctx->text_num, (void *)ctx->text_len, (void *)ctx->text_scan, (void *)ctx->text_buf, (void *)ctx->text_flag, ctx->text_ties,
                     (void *)ctx->ids[0].off, (void *)ctx->ids[0].chars, (void *)ctx->ids[1].off, (void *)ctx->ids[1].chars})
         if (b)
             (void)hipFree(b);
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
+    if (ctx->text_ties_host)
+        (void)hipHostFree(ctx->text_ties_host);
     if (ctx->scratch_free)
         (void)hipEventDestroy(ctx->scratch_free);
     if (ctx->hot_free)

@@ -69,13 +69,20 @@ struct dst_ctx {
         size_t off_bytes = 0, chars_bytes = 0;
         uint64_t n = 0;
     } ids[2];
-    void *text_res = nullptr;      // the slab's results (8 B per pair)
+    void *text_res = nullptr;      // the slab's results (8 B per pair) or tallies (<= 16 B per pair)
     void *text_num = nullptr;      // 32-byte number records
     uint32_t *text_len = nullptr;  // line lengths -> offsets
     uint32_t *text_scan = nullptr;
     char *text_buf = nullptr;
-    uint32_t *text_flag = nullptr;
+    uint32_t *text_flag = nullptr;   // [0] a value without a short text, [1] near ties noted
+    void *text_ties = nullptr;       // the slab's near ties (dst_text.hip: NearTie), device and page-locked host copies
+    void *text_ties_host = nullptr;
     size_t text_res_bytes = 0, text_num_bytes = 0, text_len_bytes = 0, text_scan_bytes = 0, text_buf_bytes = 0;
+    size_t text_ties_bytes = 0, text_ties_host_bytes = 0;
+    // the sets' {A,T,G,C} counts on the host (tn93 near ties are re-finalised there), valid while the epoch matches
+    std::vector<uint32_t> text_counts[2];
+    uint64_t text_counts_epoch[2] = {~0ull, ~0ull};
+    uint64_t text_near_ties = 0, text_patched = 0;   // running totals (dst_text_stats)
     hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;
@@ -101,6 +108,8 @@ void free_set(DeviceSet &s);
 int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
                const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists);
 int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len);
+// the per-record {A,T,G,C} counts of `s` on the device (counted by code unless the upload brought them)
+int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream);
 // rows [rb, re) of `rows` against every (square: later) record of `cols` — any two packed sets of this context
 int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet &cols, uint64_t rb, uint64_t re,
              int out_kind, void *d_out, size_t cap, void *stream_v);

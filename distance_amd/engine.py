@@ -318,6 +318,12 @@ class Engine:
                                             int(swap_ids), C.addressof(buf), capacity, C.byref(n)))
         return buf.raw[:n.value]
 
+    def text_stats(self) -> tuple[int, int]:
+        """(values the device noted as near ties of the 12th decimal, how many of them the host printed differently)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.dst_text_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def last_kernel_ms(self) -> dict:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self._check(self._lib.dst_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)))

@@ -280,8 +280,19 @@ int dst_format_distance(int measure, double as_float, int64_t as_int, char *buf,
  * from dst_host_alloc copies at link speed), *len receives its length.  At most 2^31 pairs, 65,535 rows and 4 GB of
  * text per call.  DST_ERR_CAPACITY: `capacity` is too small; DST_ERR_STATE: a value has no short text (|v| >= 1.8e7,
  * which no distance reaches): format those rows on the host.  dst_text_rect: swap_ids != 0 prints the column
- * record's id first (the value is the one dst_run_rect gives). */
+ * record's id first (the value is the one dst_run_rect gives).
+ *
+ * The text is byte for byte what the reference prints.  n / n_high / raw: the device's values are the reference's bits.
+ * jc69 / k80 / tn93 (f64::ln = the host's libm, src/measures.rs:76, 109-112, 187): the device finalises the pair's
+ * integer tallies with its own logarithm (within a few ulp of libm's) and notes every value that lies within 2^-47 |v| of
+ * a rounding boundary of the 12th decimal; those pairs (~1e-4 of a low-diversity alignment's lines) are re-finalised on
+ * the host by dst_finalize and their digits overwritten before the call returns — any value within the guard of a line
+ * that was NOT noted prints the same text.  DST_ERR_STATE also when more than 1/16 of a slab's values are near ties
+ * (distances far above 1): format that slab on the host. */
 int dst_set_ids(dst_ctx *ctx, int slot, const char *chars, const uint64_t *offsets, uint64_t n);
+/* running totals over this context's dst_text_* calls: values noted as near ties, and how many of those the host's
+ * finalisation printed differently from the device's (either pointer may be NULL) */
+int dst_text_stats(const dst_ctx *ctx, uint64_t *near_ties, uint64_t *rewritten);
 int dst_text_square(dst_ctx *ctx, int measure, uint64_t row_begin, uint64_t row_end, char *out, size_t capacity,
                     size_t *len);
 int dst_text_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t row_begin, uint64_t row_end,

@@ -78,6 +78,11 @@ def _load(native: bool = False) -> C.CDLL:
     lib.orc_all_pairs_rect.argtypes = [C.c_int, _u8p, C.c_size_t, C.c_size_t, _u64p, _u8p,
                                        C.c_size_t, C.c_size_t, _u64p, C.c_size_t, C.c_int, _f64p]
     lib.orc_all_pairs_rect.restype = C.c_int
+    lib.orc_finalize_square.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, _u64p, C.c_uint64, C.c_uint64, C.c_int, _f64p]
+    lib.orc_finalize_square.restype = C.c_int
+    lib.orc_tsv_square.argtypes = [C.c_int, _f64p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_char_p, _u64p, C.c_void_p,
+                                   C.c_uint64, C.c_int]
+    lib.orc_tsv_square.restype = C.c_uint64
     return lib
 
 
@@ -263,3 +268,37 @@ def all_pairs_rect(measure: str, a, b, counts_a=None, counts_b=None, threads: in
     if rc:
         raise RuntimeError(f"orc_all_pairs_rect rc={rc}")
     return out.reshape(a.shape[0], b.shape[0])
+
+
+# ------------------------------------------------------------------ slabs: tallies -> values -> TSV ----
+def finalize_square(measure: str, tallies, n: int, counts=None, rb: int = 0, re: int | None = None,
+                    threads: int = 1) -> np.ndarray:
+    """The tallies of rows [rb, re) of a square job (canonical order, (pairs, width) uint32) finalised like
+    measures.rs does, with libm's log: what the reference would print for them."""
+    re = n if re is None else re
+    t = np.ascontiguousarray(tallies, np.uint32)
+    t = t.reshape(len(t), -1)
+    out = np.zeros(len(t), np.float64)
+    cnt = None if counts is None else np.ascontiguousarray(counts, np.uint64)
+    rc = lib().orc_finalize_square(MEASURES[measure], t.ctypes.data, t.shape[1], n, _p64(cnt), rb, re, threads,
+                                   out.ctypes.data_as(_f64p))
+    if rc:
+        raise RuntimeError(f"orc_finalize_square rc={rc}")
+    return out
+
+
+def tsv_square(measure: str, values, ids, rb: int = 0, re: int | None = None, threads: int = 1) -> bytes:
+    """gather_write's lines (lib.rs:626-633, no header) for rows [rb, re) of a square job."""
+    n = len(ids)
+    re = n if re is None else re
+    v = np.ascontiguousarray(values, np.float64)
+    blobs = [s.encode() if isinstance(s, str) else s for s in ids]
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in blobs])
+    chars = b"".join(blobs)
+    is_int = int(measure in INT_MEASURES)
+    need = lib().orc_tsv_square(is_int, v.ctypes.data_as(_f64p), n, rb, re, chars, _p64(offs), None, 0, threads)
+    buf = C.create_string_buffer(int(need) + 1)
+    got = lib().orc_tsv_square(is_int, v.ctypes.data_as(_f64p), n, rb, re, chars, _p64(offs), C.addressof(buf), need, threads)
+    assert got == need
+    return buf.raw[:need]

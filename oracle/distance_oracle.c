@@ -616,3 +616,161 @@ int orc_all_pairs_rect(int measure, const uint8_t *a, size_t na, size_t stride_a
     free(cons);
     return 0;
 }
+
+/* ---------------------------------------------------------------- slabs: tallies -> values -> TSV ---- */
+/* The tallies of rows [rb, re) of a square job (canonical order, `width` uint32 per pair: what the engine's
+ * DST_OUT_TALLY gives) finalised like measures.rs does (orc_finalize), and gather_write's lines for such a slab
+ * (lib.rs:626-633); rows shared out over `threads`. */
+typedef struct {
+    int measure, width;
+    const uint32_t *tallies;
+    const uint64_t *counts;
+    size_t n;
+    uint64_t rb, r0, r1; /* this worker's rows [r0, r1) of the slab that starts at row rb */
+    double *out;
+    int is_int;
+    const double *values;
+    const char *id_chars;
+    const uint64_t *id_offs;
+    char *text;
+    uint64_t text_at;
+} slab_job_t;
+
+static void *finalize_rows(void *arg)
+{
+    const slab_job_t *jb = arg;
+    const uint64_t base = tri_row_start(jb->n, jb->rb);
+    for (uint64_t i = jb->r0; i < jb->r1; ++i) {
+        uint64_t p = tri_row_start(jb->n, i) - base;
+        for (uint64_t j = i + 1; j < jb->n; ++j, ++p) {
+            uint64_t tl[4] = {0, 0, 0, 0};
+            for (int k = 0; k < jb->width; ++k)
+                tl[k] = jb->tallies[p * (uint64_t)jb->width + (uint64_t)k];
+            jb->out[p] = orc_finalize(jb->measure, tl, jb->counts ? jb->counts + 4 * i : NULL,
+                                      jb->counts ? jb->counts + 4 * j : NULL);
+        }
+    }
+    return NULL;
+}
+
+/* equal pair counts, not equal row counts: the triangle's rows shrink */
+static void split_rows(slab_job_t *jobs, const slab_job_t *proto, uint64_t rb, uint64_t re, int threads)
+{
+    const uint64_t base = tri_row_start(proto->n, rb), total = tri_row_start(proto->n, re) - base;
+    uint64_t r = rb;
+    for (int k = 0; k < threads; ++k) {
+        jobs[k] = *proto;
+        jobs[k].r0 = r;
+        const uint64_t target = total * (uint64_t)(k + 1) / (uint64_t)threads;
+        while (r < re && (k == threads - 1 || tri_row_start(proto->n, r) - base < target))
+            ++r;
+        jobs[k].r1 = r;
+    }
+}
+
+static void run_slab_jobs(slab_job_t *jobs, int threads, void *(*fn)(void *))
+{
+    pthread_t *tid = calloc((size_t)threads, sizeof *tid);
+    for (int k = 1; k < threads; ++k)
+        pthread_create(&tid[k], NULL, fn, &jobs[k]);
+    fn(&jobs[0]);
+    for (int k = 1; k < threads; ++k)
+        pthread_join(tid[k], NULL);
+    free(tid);
+}
+
+int orc_finalize_square(int measure, const uint32_t *tallies, int width, size_t n, const uint64_t *counts,
+                        uint64_t rb, uint64_t re, int threads, double *out)
+{
+    if (measure < ORC_N || measure > ORC_TN93 || width < 1 || width > 4 || re > n || rb > re)
+        return -1;
+    if (threads < 1)
+        threads = 1;
+    slab_job_t proto = {0};
+    proto.measure = measure;
+    proto.width = width;
+    proto.tallies = tallies;
+    proto.counts = counts;
+    proto.n = n;
+    proto.rb = rb;
+    proto.out = out;
+    slab_job_t *jobs = calloc((size_t)threads, sizeof *jobs);
+    split_rows(jobs, &proto, rb, re, threads);
+    run_slab_jobs(jobs, threads, finalize_rows);
+    free(jobs);
+    return 0;
+}
+
+/* the lines of rows [r0, r1); text == NULL only measures them */
+static uint64_t tsv_rows(const slab_job_t *jb, char *text)
+{
+    const uint64_t base = tri_row_start(jb->n, jb->rb);
+    uint64_t at = 0;
+    char num[64];
+    for (uint64_t i = jb->r0; i < jb->r1; ++i) {
+        const char *id1 = jb->id_chars + jb->id_offs[i];
+        const size_t l1 = (size_t)(jb->id_offs[i + 1] - jb->id_offs[i]);
+        uint64_t p = tri_row_start(jb->n, i) - base;
+        for (uint64_t j = i + 1; j < jb->n; ++j, ++p) {
+            const size_t l2 = (size_t)(jb->id_offs[j + 1] - jb->id_offs[j]);
+            const int ln = jb->is_int ? orc_format_int((int64_t)jb->values[p], num, sizeof num)
+                                      : orc_format_float(jb->values[p], num, sizeof num);
+            if (text) {
+                char *o = text + at;
+                memcpy(o, id1, l1);
+                o[l1] = '\t';
+                memcpy(o + l1 + 1, jb->id_chars + jb->id_offs[j], l2);
+                o[l1 + 1 + l2] = '\t';
+                memcpy(o + l1 + l2 + 2, num, (size_t)ln);
+                o[l1 + l2 + 2 + (size_t)ln] = '\n';
+            }
+            at += l1 + l2 + (uint64_t)ln + 3;
+        }
+    }
+    return at;
+}
+
+static void *tsv_measure(void *arg)
+{
+    slab_job_t *jb = arg;
+    jb->text_at = tsv_rows(jb, NULL);
+    return NULL;
+}
+
+static void *tsv_write(void *arg)
+{
+    slab_job_t *jb = arg;
+    tsv_rows(jb, jb->text + jb->text_at);
+    return NULL;
+}
+
+/* returns the length of the text; nothing is written when it exceeds cap */
+uint64_t orc_tsv_square(int is_int, const double *values, size_t n, uint64_t rb, uint64_t re, const char *id_chars,
+                        const uint64_t *id_offs, char *out, uint64_t cap, int threads)
+{
+    if (re > n || rb > re)
+        return 0;
+    if (threads < 1)
+        threads = 1;
+    slab_job_t proto = {0};
+    proto.is_int = is_int;
+    proto.values = values;
+    proto.n = n;
+    proto.rb = rb;
+    proto.id_chars = id_chars;
+    proto.id_offs = id_offs;
+    proto.text = out;
+    slab_job_t *jobs = calloc((size_t)threads, sizeof *jobs);
+    split_rows(jobs, &proto, rb, re, threads);
+    run_slab_jobs(jobs, threads, tsv_measure);
+    uint64_t total = 0;
+    for (int k = 0; k < threads; ++k) {
+        const uint64_t len = jobs[k].text_at;
+        jobs[k].text_at = total;
+        total += len;
+    }
+    if (out && total <= cap)
+        run_slab_jobs(jobs, threads, tsv_write);
+    free(jobs);
+    return total;
+}

@@ -101,6 +101,17 @@ int orc_all_pairs_rect(int measure, const uint8_t *a, size_t na, size_t stride_a
                        const uint64_t *counts_a, const uint8_t *b, size_t nb, size_t stride_b,
                        const uint64_t *counts_b, size_t len, int threads, double *out);
 
+/*
+ * Slab checkers for the engine's TSV text: the tallies of rows [rb, re) of a square job (canonical order,
+ * `width` uint32 per pair) finalised with orc_finalize (measures.rs:68, 76, 109-112, 118-190; libm's log),
+ * and gather_write's lines for such a slab (lib.rs:626-633: "id1\tid2\tvalue\n", `{}` / `{:.12}`).
+ * orc_tsv_square returns the text's length and writes it only when it fits cap.
+ */
+int orc_finalize_square(int measure, const uint32_t *tallies, int width, size_t n, const uint64_t *counts,
+                        uint64_t rb, uint64_t re, int threads, double *out);
+uint64_t orc_tsv_square(int is_int, const double *values, size_t n, uint64_t rb, uint64_t re, const char *id_chars,
+                        const uint64_t *id_offs, char *out, uint64_t cap, int threads);
+
 #ifdef __cplusplus
 }
 #endif

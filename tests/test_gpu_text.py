@@ -1,13 +1,16 @@
 """GPU (-m gpu): the TSV text produced on the device (dst_text_square / dst_text_rect, dst_text.hip) against the text
 the reference's gather_write prints (src/lib.rs:612-644): ids, tabs, `{}` for n / n_high and `{:.12}` for the others
-incl. "NaN", "inf", "-inf" and "-0.000000000000" — here built from the engine's own results with Python's
-correctly rounded fixed formatting (the C formatter dst_format_distance is checked against libc elsewhere)."""
+incl. "NaN", "inf", "-inf" and "-0.000000000000".  The expected text is built from the ORACLE's values (the reference's
+finalisation with libm's log, oracle.all_pairs_*) with Python's correctly rounded fixed formatting: the device text
+must be the reference's bytes, not a formatting of whatever the device computed (tests/test_gpu_text_identity.py counts
+the lines at BASELINE's C2 size)."""
 import math
 
 import numpy as np
 import pytest
 
 import distance_amd as da
+import oracle
 from helpers import random_alignment, uniform_codes
 
 pytestmark = pytest.mark.gpu
@@ -51,7 +54,9 @@ def test_square_text_equals_the_reference_format(eng):
     eng.upload(0, codes)
     eng.set_ids(0, ids)
     for m in ALL:
-        values = eng.run_square(m)
+        values = oracle.all_pairs_square(m, codes)
+        dev = eng.run_square(m)
+        assert np.allclose(dev, values, rtol=0, atol=1e-12, equal_nan=True)
         assert eng.text_square(m, 0, 140) == expected_square(m, values, ids, 0, 140), m
         lo = da.square_row_start(140, 50) - da.square_row_start(140, 0)
         hi = da.square_row_start(140, 57) - da.square_row_start(140, 0)
@@ -66,8 +71,9 @@ def test_many_distinct_decimals(eng):
     ids = ["s%d" % k for k in range(700)]
     eng.upload(0, codes)
     eng.set_ids(0, ids)
-    for m in ("raw", "jc69", "tn93"):
-        values = eng.run_square(m, 0, 300)
+    last = da.square_row_start(700, 300)
+    for m in ("raw", "jc69", "k80", "tn93"):
+        values = oracle.all_pairs_square(m, codes, pair_range=(0, last), threads=8)
         assert eng.text_square(m, 0, 300) == expected_square(m, values, ids, 0, 300), m
 
 
@@ -78,8 +84,8 @@ def test_rectangle_text_and_swapped_ids(eng):
     eng.upload(1, b)
     eng.set_ids(0, ids_a)
     eng.set_ids(1, ids_b)
-    for m in ("n_high", "k80"):
-        values = eng.run_rect(m, 0, 1).reshape(31, 45)
+    for m in ("n_high", "k80", "tn93"):
+        values = oracle.all_pairs_rect(m, a, b)
         want = "".join(f"{ids_a[i]}\t{ids_b[j]}\t{field(m, values[i, j])}\n" for i in range(4, 20) for j in range(45))
         assert eng.text_rect(m, 0, 1, 4, 20) == want.encode()
         swapped = "".join(f"{ids_b[j]}\t{ids_a[i]}\t{field(m, values[i, j])}\n" for i in range(4, 20) for j in range(45))
