@@ -6,9 +6,9 @@ The product is ``libdistance_hip.so`` (hand-written gfx950 HIP kernels behind th
 tests and ``bench.py``.  It never imports ``oracle`` and has no CPU compute path.
 """
 from ._lib import DistanceError, LIB_PATH, declared_symbols, load
-from .engine import (OUT_DISTANCE, OUT_TALLY, OUT_TALLY16, FLOAT_MEASURES, INT_MEASURES, MEASURES, Engine, finalize, format_distance,
-                     partition_rect, partition_square, plan_tiles, square_pairs, square_row_start, tally_width)
+from .engine import (OUT_DISTANCE, OUT_TALLY, OUT_TALLY16, FLOAT_MEASURES, INT_MEASURES, MEASURES, Comm, Engine, finalize, format_distance,
+                     partition_rect, partition_square, plan_tiles, shared_range, square_pairs, square_row_start, tally_width)
 
-__all__ = ["DistanceError", "Engine", "MEASURES", "INT_MEASURES", "FLOAT_MEASURES", "LIB_PATH",
+__all__ = ["DistanceError", "Engine", "Comm", "shared_range", "MEASURES", "INT_MEASURES", "FLOAT_MEASURES", "LIB_PATH",
            "declared_symbols", "load", "finalize", "format_distance", "partition_square",
            "partition_rect", "plan_tiles", "square_pairs", "square_row_start", "tally_width"]

@@ -17,6 +17,7 @@ _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
 _u64p = C.POINTER(C.c_uint64)
 _vp = C.c_void_p
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 SLAB_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
 
 
@@ -76,7 +77,11 @@ _SIGS = {
     "dst_stream_close": (C.c_int, [_vp]),
     "dst_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "dst_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dst_comm_create_custom": (C.c_int, [_vp, C.c_int, C.c_int, ALLGATHER_FN, _vp, C.POINTER(_vp)]),
     "dst_comm_destroy": (C.c_int, [_vp]),
+    "dst_upload_shared": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _vp]),
+    "dst_shared_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
+    "dst_shared_stats": (C.c_int, [_vp, C.c_int, _u64p, _u64p, _u64p]),
     "dst_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dst_gather_slabs": (C.c_int, [_vp, _vp, _vp, _u64p, _u64p, C.c_int, _vp]),
     "dst_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),

@@ -90,8 +90,10 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.loaded = false;
     s.have_counts = false;
     s.lean = false;
+    s.partial = false;
+    s.part_begin = s.part_end = 0;
     s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
-    s.ref.valid = s.rec.valid = s.site.valid = s.rec.pre_valid = false;
+    s.ref.valid = s.rec.valid = s.site.valid = s.rec.pre_valid = s.rec.ranges_valid = false;
     s.aconst_family = -1;
     return DST_OK;
 }
@@ -117,10 +119,6 @@ int alloc_ref(dst_ctx *ctx, DeviceSet &s)
     s.ref.nchunks = s.nchunks;
     return DST_OK;
 }
-
-// Lists are only worth counting while the sampled records deviate from the reference at less than this share of the
-// sites (unstructured data crosses over to the dense path near 3-4 %; profiles/r02/consensus_calibration.txt)
-constexpr double kListsMaxDeviation = 0.08;
 
 // queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the first
 // offending byte's index (or stays ~0).  Nothing here waits for the device.
@@ -232,6 +230,9 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
 // the dense pair kernels read all eight planes: build the four derived ones of a set that was packed lean
 int ensure_derived(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
+    if (s.partial)
+        return fail(ctx, DST_ERR_STATE, "a set uploaded with dst_upload_shared runs on the consensus path only (this rank holds "
+                                        "the planes of its own records)");
     if (!s.lean)
         return DST_OK;
     int rc = wait_for_other_runs(ctx, stream);
@@ -246,6 +247,9 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
     if (s.have_counts)
         return DST_OK;
+    if (s.partial)
+        return fail(ctx, DST_ERR_STATE, "the set was uploaded with dst_upload_shared without base counts (with_counts = 0): this rank "
+                                        "holds the planes of its own records only");
     HIP_TRY(ctx, launch_fill_counts(s, stream));
     // later runs may be queued on OTHER streams (multi-GPU sub-slabs alternate between two): they wait for this on
     // the device (order_after_prep)
@@ -465,6 +469,25 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     // 32 bytes of lookup table per (site, panel); bucket numbers travel as 32-bit values
     if (n_buckets >= 0xFFFFFFFFull || n_buckets * 2 * sizeof(uint4) > (16ull << 30))
         return fail(ctx, DST_ERR_CAPACITY, "too many sites x panels for the consensus path's lookup table");
+    if (lists_ok && s.rec.ranges_valid) {
+        // the lists are there with their range marks (they came by dst_upload_shared's exchange): only the site buckets
+        rc = ensure_bytes(ctx, (void **)&s.site.inl, &s.site.inl_cap, std::max<size_t>(n_buckets, 1) * 2 * sizeof(uint4));
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&s.site.ent, &s.site.ent_cap, std::max<size_t>(s.rec.total, 1) * sizeof(uint32_t));
+        if (rc)
+            return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, launch_site_buckets(s, n_panels, reinterpret_cast<uint32_t *>(ctx->d_total + 1), stream));
+        rc = publish_prep(ctx, stream);
+        if (rc)
+            return rc;
+        s.site.valid = true;
+        s.site.n_panels = n_panels;
+        return DST_OK;
+    }
+    if (s.partial)
+        return fail(ctx, DST_ERR_STATE, "a set uploaded with dst_upload_shared holds the lists the exchange brought; they cannot be "
+                                        "rebuilt here (another reference, the hybrid path): upload it with dst_upload_device");
     rc = ensure_bytes(ctx, (void **)&s.rec.off, &s.rec.off_cap, (s.n + 1) * sizeof(uint32_t));
     if (!rc && want_sites)
         rc = ensure_bytes(ctx, (void **)&s.site.inl, &s.site.inl_cap, std::max<size_t>(n_buckets, 1) * 2 * sizeof(uint4));
@@ -473,6 +496,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (rc)
         return rc;
     s.rec.valid = false;
+    s.rec.ranges_valid = false;
     s.site.valid = false;
     uint32_t *d_ovf_n = reinterpret_cast<uint32_t *>(ctx->d_total + 1);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
@@ -521,6 +545,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     if (rc)
         return rc;
     s.rec.valid = true;
+    s.rec.ranges_valid = want_sites;
     s.rec.ref_owner = &refset;
     s.rec.ref_epoch = refset.epoch;
     s.rec.without_hot = without_hot;
@@ -665,7 +690,12 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
     int path = DST_PATH_DENSE;
     // a launch the dense kernels finish in less time than the lists take to set up goes dense unasked
     const bool tiny = ctx->path == DST_PATH_AUTO && (double)total_pairs * (double)cols.len < ctx->prep_min_work && !cols.ref.valid;
-    if (ctx->path != DST_PATH_DENSE && !tiny && consensus_shape_ok(rows, cols)) {
+    // a set whose preparation was shared out over the ranks (dst_upload_shared) has the lists of every record but only
+    // this rank's planes: the consensus path, whatever the cost model would say
+    const bool partial = rows.partial || cols.partial;
+    if (partial && (ctx->path == DST_PATH_DENSE || ctx->path == DST_PATH_HYBRID))
+        return fail(ctx, DST_ERR_STATE, "a set uploaded with dst_upload_shared runs on the consensus path only");
+    if (ctx->path != DST_PATH_DENSE && (!tiny || partial) && consensus_shape_ok(rows, cols)) {
         rc = ensure_lut(ctx);
         if (!rc)
             rc = ensure_ref(ctx, cols, stream);
@@ -673,7 +703,7 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             return rc;
         const uint64_t n_panels = (cols.n + kPanelCols - 1) / kPanelCols;
         const uint64_t tiles_est = std::max<uint64_t>(1, n_panels * ((re - rb + kConsensusRowsPerTile - 1) / kConsensusRowsPerTile) / (square ? 2 : 1));
-        path = ctx->path != DST_PATH_AUTO ? ctx->path
+        path = partial ? DST_PATH_CONSENSUS : ctx->path != DST_PATH_AUTO ? ctx->path
                                           : cheapest_path(rows, cols, measure, total_pairs, (uint32_t)std::min<uint64_t>(tiles_est, 0xFFFFFFFFu),
                                                           (double)total_pairs / (double)std::max<uint64_t>(pairs_in_rows(square, cols.n, 0, rows.n), 1));
         const uint64_t n_hot = cols.ref.h_stats[4];
@@ -684,7 +714,7 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             rc = ensure_index(ctx, cols, cols, true, without_hot, stream);
             if (!rc && &rows != &cols)
                 rc = ensure_index(ctx, rows, cols, false, without_hot, stream);
-            if (rc == DST_ERR_CAPACITY)
+            if (rc == DST_ERR_CAPACITY && !partial)
                 path = DST_PATH_DENSE;  // denser than the lists can index: the dense path handles any input
             else if (rc)
                 return rc;
@@ -992,6 +1022,10 @@ int dst_destroy(dst_ctx *ctx)
     for (auto &s : ctx->schedules)
         if (s.d_blocks)
             (void)hipFree(s.d_blocks);
+    for (auto &sh : ctx->shared)
+        for (void *b : {sh.send, sh.recv, (void *)sh.off_local})
+            if (b)
+                (void)hipFree(b);
     for (void *b : {(void *)ctx->d_lut, (void *)ctx->d_total, (void *)ctx->scan_tmp, ctx->host_out, ctx->hot_tally, ctx->text_res,
                     ctx->text_num, (void *)ctx->text_len, (void *)ctx->text_scan, (void *)ctx->text_buf, (void *)ctx->text_flag, ctx->text_ties,
                     (void *)ctx->ids[0].off, (void *)ctx->ids[0].chars, (void *)ctx->ids[1].off, (void *)ctx->ids[1].chars})
@@ -1156,6 +1190,8 @@ int dst_consensus(dst_ctx *ctx, int both_slots, uint8_t *cons, size_t cap)
     if (!a.loaded)
         return fail(ctx, DST_ERR_STATE, "set not uploaded");
     const bool two = both_slots && ctx->set[1].loaded;
+    if (a.partial || (two && ctx->set[1].partial))
+        return fail(ctx, DST_ERR_STATE, "not available for a set uploaded with dst_upload_shared (this rank holds the planes of its own records only)");
     if (two && ctx->set[1].len != a.len)
         return fail(ctx, DST_ERR_STATE, "Different length sequences in alignment(s)");
     if (cap < a.len)
@@ -1204,6 +1240,10 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     DeviceSet &s = ctx->set[slot];
     if (!s.loaded)
         return fail(ctx, DST_ERR_STATE, "set not uploaded");
+    if (s.partial)
+        return fail(ctx, DST_ERR_STATE, "not available for a set uploaded with dst_upload_shared (this rank holds the planes of its own records only)");
+    if (len >= kSiteMask)   // the list entries carry the site in kSiteBits bits
+        return fail(ctx, DST_ERR_CAPACITY, "alignments of 2^25 sites or more are beyond dst_differences");
     if (len != s.len) {
         char msg[128];
         std::snprintf(msg, sizeof msg, "Different length sequences in alignment(s): %zu vs %zu", len, s.len);

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint32_t *__restrict
 __device__ __forceinline__ void emit_chunk_by_wave(const uint4 *__restrict__ planes, const uint4 *__restrict__ ref_planes,
                                                    const uint4 *__restrict__ hot_planes, bool skip_nclass, size_t ps,
                                                    uint32_t nchunks, uint32_t npad, uint32_t rs, uint32_t cs, uint32_t out0,
-                                                   uint32_t lane, uint32_t *__restrict__ rec_ent)
+                                                   uint32_t lane, uint32_t *__restrict__ rec_ent, uint32_t ent_cap = 0xFFFFFFFFu)
 {
     const uint32_t w = lane >> 4, b0 = (lane & 15u) * 2u;
     const size_t wa = ((size_t)cs * npad + rs) * 4u + w;
@@ -337,7 +337,8 @@ __device__ __forceinline__ void emit_chunk_by_wave(const uint4 *__restrict__ pla
         if (dm >> bit & 1u) {
             const uint32_t nib = ((a >> bit) & 1u) << 3 | ((g >> bit) & 1u) << 2 | ((cc >> bit) & 1u) << 1 | ((t >> bit) & 1u);
             const uint32_t rnib = ((ra >> bit) & 1u) << 3 | ((rg >> bit) & 1u) << 2 | ((rc >> bit) & 1u) << 1 | ((rt >> bit) & 1u);
-            rec_ent[pos] = (cs * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
+            if (pos < ent_cap)
+                rec_ent[pos] = (cs * kChunkSites + 32u * w + bit) | (uint32_t)ref_class(rnib) << kSiteBits | nib << kEntryShift;
             ++pos;
         }
     }
@@ -483,16 +484,18 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                                                         const uint4 *__restrict__ hot_planes, uint32_t n,
                                                         uint32_t nchunks, uint32_t npad,
                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
-                                                        uint32_t *__restrict__ range_start)
+                                                        uint32_t *__restrict__ range_start, uint32_t rec_first, uint32_t ent_cap)
 {
+    // records [rec_first, n) (rec_off[0] is record rec_first's offset); entries at or beyond ent_cap are not written:
+    // one rank's share of a set, whose lists go into an exchange block of fixed size (dst_upload_shared)
     constexpr uint32_t RLN = 64u / CLN;
     const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t rl = lane % RLN, cl = lane / RLN;
-    const uint32_t r = wave * RLN + rl;
+    const uint32_t r = rec_first + wave * RLN + rl;
     const bool live = r < n;
     const size_t ps = (size_t)nchunks * npad;
     uint32_t run = 0;
-    const uint32_t base0 = live ? rec_off[r] : 0u;
+    const uint32_t base0 = live ? rec_off[r - rec_first] : 0u;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     // two steps ahead
     uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
             emit_chunk_by_wave(planes, ref_planes, WITHOUT_HOT ? hot_planes : nullptr, false, ps, nchunks, npad,
-                               wave * RLN + src % RLN, c0 + src / RLN, __shfl(at0, src), lane, rec_ent);
+                               rec_first + wave * RLN + src % RLN, c0 + src / RLN, __shfl(at0, src), lane, rec_ent, ent_cap);
         }
         if (pc && !big) {
             uint32_t at = at0;
@@ -562,7 +565,9 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                 for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                     const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
                     if (k <= cnt_all && !(e >> 14 & 1u)) {
-                        rec_ent[at++] = (c * kChunkSites + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
+                        if (at < ent_cap)
+                            rec_ent[at] = (c * kChunkSites + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
+                        ++at;
                     }
                 }
             } else {
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
 #pragma unroll
                 for (uint32_t k = 1; k <= kSlotEntries; ++k) {
                     const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
-                    if (k <= cnt_all) {
+                    if (k <= cnt_all && at + k - 1 < ent_cap) {
                         ep[k - 1] = (site0 + (e & 127u)) | ((e >> 7) & 7u) << kSiteBits | ((e >> 10) & 15u) << kEntryShift;
                     }
                 }
@@ -1566,6 +1571,105 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
 }
 
 // =============================================================================================
+// shared preparation (dst_upload_shared): every rank packs and lists 1/world of the records, ONE all-gather of
+// fixed-size blocks carries the lists (and counts) to everybody, and each rank splices them into the set's CSR
+// =============================================================================================
+// the block's header, list lengths (and zero padding up to the layout's records per rank) from the rank's own pass
+__global__ __launch_bounds__(256) void shared_block_kernel(uint32_t *__restrict__ block, SharedLayout lay, uint32_t rec_first,
+                                                           uint32_t count, const uint32_t *__restrict__ cnt_cold,
+                                                           const uint32_t *__restrict__ cnt_hot,
+                                                           const uint32_t *__restrict__ off_local,
+                                                           const unsigned long long *__restrict__ first_bad)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < lay.rmax)
+        block[lay.cnt_at + i] = i < count ? cnt_cold[rec_first + i] + cnt_hot[rec_first + i] : 0u;
+    if (i < 16) {
+        const uint32_t total = off_local[count];
+        const unsigned long long bad = *first_bad;
+        const uint32_t hdr[4] = {total, total > lay.ent_cap ? 1u : 0u, (uint32_t)bad, (uint32_t)(bad >> 32)};
+        block[i] = i < 4 ? hdr[i] : 0u;
+    }
+}
+
+// every record's list length (and counts) from the gathered blocks, in record order; len_all[n] = 0 for the scan
+__global__ __launch_bounds__(256) void shared_lengths_kernel(const uint32_t *__restrict__ gathered, SharedLayout lay, uint32_t n,
+                                                             uint32_t *__restrict__ len_all, uint32_t *__restrict__ counts)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r > n)
+        return;
+    if (r == n) {
+        len_all[n] = 0;
+        return;
+    }
+    const uint32_t k = r / lay.rmax, i = r - k * lay.rmax;
+    const uint32_t *blk = gathered + (size_t)k * lay.words;
+    len_all[r] = blk[lay.cnt_at + i];
+    if (counts)
+        reinterpret_cast<uint4 *>(counts)[r] = reinterpret_cast<const uint4 *>(blk + lay.counts_at)[i];
+}
+
+// rank blockIdx.y's entries to their place in the CSR (its first record's offset)
+// (ent_room: what rec_ent holds — when a rank's lists did not fit its block the offsets run past it, and the upload fails)
+__global__ __launch_bounds__(256) void shared_entries_kernel(const uint32_t *__restrict__ gathered, SharedLayout lay, uint32_t n,
+                                                             const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
+                                                             uint32_t ent_room)
+{
+    const uint32_t k = blockIdx.y;
+    const uint32_t *blk = gathered + (size_t)k * lay.words;
+    const uint32_t total = min(blk[0], lay.ent_cap);
+    const uint32_t base = rec_off[min((uint32_t)((uint64_t)k * lay.rmax), n)];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256)
+        if (base + i < ent_room)
+            rec_ent[base + i] = blk[lay.ent_at + i];
+}
+
+// where every record's list crosses each multiple of kBucketSites sites (what the fill passes note on their way)
+__global__ __launch_bounds__(256) void range_marks_kernel(const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_ent,
+                                                          uint32_t n, uint32_t npad, uint32_t *__restrict__ range_start,
+                                                          uint32_t ent_room)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (r >= n)
+        return;
+    uint32_t lo = min(rec_off[r], ent_room), hi = min(rec_off[r + 1], ent_room);
+    const uint32_t site = g * kBucketSites;
+    while (lo < hi) {   // first entry at or beyond `site`
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((rec_ent[mid] & kSiteMask) < site)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    range_start[(size_t)g * npad + r] = lo;
+}
+
+// what the host reads after a shared upload: [0] first invalid byte over all ranks, [1..8] the sample's statistics,
+// [9] list entries of the whole set, [10] ranks whose lists did not fit their block, [11] the largest block's entries
+__global__ __launch_bounds__(64) void shared_report_kernel(const uint32_t *__restrict__ gathered, SharedLayout lay,
+                                                           const unsigned long long *__restrict__ stats, unsigned long long *report)
+{
+    if (threadIdx.x >= 1 && threadIdx.x <= 8)
+        report[threadIdx.x] = stats[threadIdx.x - 1];
+    if (threadIdx.x != 0)
+        return;
+    unsigned long long bad = ~0ull, total = 0, over = 0, biggest = 0;
+    for (uint32_t k = 0; k < lay.world; ++k) {
+        const uint32_t *blk = gathered + (size_t)k * lay.words;
+        const unsigned long long b = (unsigned long long)blk[2] | (unsigned long long)blk[3] << 32;
+        bad = b < bad ? b : bad;
+        total += blk[0];
+        over += blk[1];
+        biggest = blk[0] > biggest ? blk[0] : biggest;
+    }
+    report[0] = bad;
+    report[9] = total;
+    report[10] = over;
+    report[11] = biggest;
+}
+
+// =============================================================================================
 // exact per-site counts for consensus() (src/fastaio.rs:289-336)
 // =============================================================================================
 // hist[site][3] += records of this block's range whose code at the site is G, C, T (72, 40, 24); every
@@ -1651,18 +1755,23 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uin
 }
 
 hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
-                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream)
+                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream, size_t rec_begin,
+                            size_t rec_end, uint32_t ent_cap)
 {
     // waves of 8 records x 8 chunks when that makes enough of them, else 4 x 16 or 2 x 32 (see the kernel)
-    const uint32_t n = (uint32_t)set.n, nch = (uint32_t)set.nchunks, npad = (uint32_t)set.npad;
+    const uint32_t first = (uint32_t)std::min(rec_begin, set.n), n = (uint32_t)std::min(rec_end, set.n);
+    const uint32_t nch = (uint32_t)set.nchunks, npad = (uint32_t)set.npad, count = n - first;
+    if (n <= first)
+        return hipSuccess;
     auto go = [&](auto cln, auto wh) {
         constexpr uint32_t CLN = decltype(cln)::value;
         constexpr uint32_t per_block = 4u * (64u / CLN);
-        hipLaunchKernelGGL((slot_fill_kernel<CLN, decltype(wh)::value>), dim3((n + per_block - 1) / per_block), dim3(256), 0, stream,
-                           set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, range_start);
+        hipLaunchKernelGGL((slot_fill_kernel<CLN, decltype(wh)::value>), dim3((count + per_block - 1) / per_block), dim3(256), 0, stream,
+                           set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, range_start, first,
+                           ent_cap);
     };
     using std::integral_constant;
-    const uint32_t cln = n >= 32768 ? 8u : n >= 16384 ? 16u : 32u;
+    const uint32_t cln = count >= 32768 ? 8u : count >= 16384 ? 16u : 32u;
     if (without_hot) {
         if (cln == 8) go(integral_constant<uint32_t, 8>{}, std::true_type{});
         else if (cln == 16) go(integral_constant<uint32_t, 16>{}, std::true_type{});
@@ -1807,6 +1916,36 @@ hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const 
     }
 #undef DST_FAM
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_shared_block(uint32_t *block, const SharedLayout &lay, const DeviceSet &set, size_t rec_begin, size_t count,
+                               const uint32_t *off_local, const unsigned long long *first_bad, hipStream_t stream)
+{
+    hipLaunchKernelGGL(shared_block_kernel, dim3((lay.rmax + 255) / 256), dim3(256), 0, stream, block, lay, (uint32_t)rec_begin,
+                       (uint32_t)count, set.rec.pre_cold, set.rec.pre_hot, off_local, first_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_shared_splice(const uint32_t *gathered, const SharedLayout &lay, DeviceSet &set, uint32_t *len_all,
+                                uint32_t *scan_tmp, bool with_counts, unsigned long long *report, hipStream_t stream)
+{
+    const uint32_t n = (uint32_t)set.n, npad = (uint32_t)set.npad;
+    const uint32_t ent_room = (uint32_t)std::min<size_t>(set.rec.ent_cap / sizeof(uint32_t), 0xFFFFFFFFu);
+    hipLaunchKernelGGL(shared_lengths_kernel, dim3((n + 256) / 256), dim3(256), 0, stream, gathered, lay, n, len_all,
+                       with_counts ? set.counts : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = launch_exclusive_scan(set.rec.off, (size_t)n + 1, scan_tmp, stream, len_all);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(shared_entries_kernel, dim3(std::max(1u, std::min(256u, lay.ent_cap / 1024u + 1u)), lay.world), dim3(256), 0,
+                       stream, gathered, lay, n, set.rec.off, set.rec.ent, ent_room);
+    const uint32_t n_ranges = (uint32_t)((set.nchunks * kChunkSites + kBucketSites - 1) / kBucketSites);
+    hipLaunchKernelGGL(range_marks_kernel, dim3((n + 255) / 256, n_ranges), dim3(256), 0, stream, set.rec.off, set.rec.ent, n, npad,
+                       set.rec.range_start, ent_room);
+    hipLaunchKernelGGL(shared_report_kernel, dim3(1), dim3(64), 0, stream, gathered, lay,
+                       reinterpret_cast<const unsigned long long *>(set.ref.stats), report);
+    return hipGetLastError();
 }
 
 hipError_t launch_site_hist(const DeviceSet &set, uint32_t *hist, hipStream_t stream)

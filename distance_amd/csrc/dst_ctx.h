@@ -83,13 +83,27 @@ struct dst_ctx {
     std::vector<uint32_t> text_counts[2];
     uint64_t text_counts_epoch[2] = {~0ull, ~0ull};
     uint64_t text_near_ties = 0, text_patched = 0;   // running totals (dst_text_stats)
+    // dst_upload_shared (dst_shared.cpp): this rank's exchange block, everybody's blocks, and what the last exchange told
+    struct Shared {
+        void *send = nullptr, *recv = nullptr;
+        uint32_t *off_local = nullptr;
+        size_t send_bytes = 0, recv_bytes = 0, off_local_bytes = 0;
+        uint64_t last_biggest = 0;   // entries of the largest block of the previous shared upload (sizes the next one)
+        uint64_t uploads = 0, fallbacks = 0;
+    } shared[2];
     hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;
     std::string err;
 };
 
+struct dst_comm;
+
 namespace dst {
+
+// Lists are only worth counting while the sampled records deviate from the reference at less than this share of the
+// sites (unstructured data crosses over to the dense path near 3-4 %; profiles/r02/consensus_calibration.txt)
+constexpr double kListsMaxDeviation = 0.08;
 
 int fail(dst_ctx *ctx, int status, const std::string &msg);
 int fail_hip(dst_ctx *ctx, hipError_t e, const char *what);

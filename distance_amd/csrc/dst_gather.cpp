@@ -31,6 +31,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -62,6 +63,7 @@ void load_rccl()
     g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
     g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
     g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
 }
 
@@ -75,7 +77,9 @@ bool rccl_ready()
 
 struct dst_comm {
     dst_ctx *ctx = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;        // RCCL transport (dst_comm_create) ...
+    dst_allgather_fn custom = nullptr;  // ... or the caller's own (dst_comm_create_custom: MPI, gloo in the rehearsal tests)
+    void *custom_user = nullptr;
     int rank = 0, world = 1;
 };
 
@@ -88,7 +92,48 @@ int fail_rccl(dst_ctx *ctx, ncclResult_t r, const char *what)
 
 }  // namespace
 
+namespace dst {
+
+dst_ctx *comm_ctx(dst_comm *c) { return c->ctx; }
+int comm_rank(const dst_comm *c) { return c->rank; }
+int comm_world(const dst_comm *c) { return c->world; }
+
+// every rank's `bytes` at d_send -> d_recv[rank * bytes ...) on every rank, ordered on `stream`
+int comm_allgather(dst_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t stream)
+{
+    dst_ctx *ctx = c->ctx;
+    if (c->world == 1) {
+        if (d_recv != d_send)
+            HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, stream));
+        return DST_OK;
+    }
+    if (c->custom) {
+        const int rc = c->custom(c->custom_user, d_send, d_recv, bytes, (void *)stream);
+        return rc == 0 ? DST_OK : fail(ctx, DST_ERR_HIP, "the communicator's all-gather callback failed");
+    }
+    const ncclResult_t res = g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c->comm, stream);
+    return res == ncclSuccess ? DST_OK : fail_rccl(ctx, res, "ncclAllGather");
+}
+
+}  // namespace dst
+
 extern "C" {
+
+int dst_comm_create_custom(dst_ctx *ctx, int rank, int world, dst_allgather_fn fn, void *user, dst_comm **out)
+{
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        return DST_ERR_ARG;
+    dst_comm *c = new (std::nothrow) dst_comm;
+    if (!c)
+        return DST_ERR_NOMEM;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->custom = fn;
+    c->custom_user = user;
+    *out = c;
+    return DST_OK;
+}
 
 int dst_comm_unique_id(uint8_t *id, size_t cap)
 {
@@ -157,6 +202,8 @@ int dst_gather_slabs(dst_comm *c, const void *d_local, void *d_full, const uint6
     if (!c || !byte_offsets || !byte_sizes || root < 0 || root >= c->world)
         return DST_ERR_ARG;
     dst_ctx *ctx = c->ctx;
+    if (!c->comm && c->world > 1)
+        return fail(ctx, DST_ERR_STATE, "dst_gather_slabs needs an RCCL communicator (dst_comm_create)");
     const uint64_t mine = byte_sizes[c->rank];
     if ((mine && !d_local) || (c->rank == root && !d_full))
         return fail(ctx, DST_ERR_ARG, "null slab pointer");

@@ -120,6 +120,22 @@ std::vector<BlockDesc> build_blocks(bool square, uint64_t row_begin, uint64_t ro
     return out;
 }
 
+// ---- shared preparation: which records a rank prepares, and the shape of its exchange block ------------
+// every rank takes rmax records (a multiple of 256: whole waves of the pack), the last ranks possibly fewer or none
+SharedLayout shared_layout(uint64_t n, int world, uint32_t ent_cap)
+{
+    SharedLayout lay{};
+    lay.world = (uint32_t)world;
+    const uint64_t per = (n + (uint64_t)world - 1) / (uint64_t)world;
+    lay.rmax = (uint32_t)((per + 255) / 256 * 256);
+    lay.cnt_at = 16;
+    lay.counts_at = lay.cnt_at + lay.rmax;
+    lay.ent_at = lay.counts_at + 4 * lay.rmax;
+    lay.ent_cap = (ent_cap + 3u) & ~3u;
+    lay.words = lay.ent_at + lay.ent_cap;
+    return lay;
+}
+
 // ---- consensus-delta path: per-site semantics, tables, tiles ---------------------------------------
 
 int family_of(int measure)
@@ -362,6 +378,16 @@ int dst_partition_rect(uint64_t n_rows, int parts, uint64_t *bounds)
         return DST_ERR_ARG;
     for (int k = 0; k <= parts; ++k)
         bounds[k] = (uint64_t)(((unsigned __int128)n_rows * (unsigned)k) / (unsigned)parts);
+    return DST_OK;
+}
+
+int dst_shared_range(uint64_t n, int rank, int world, uint64_t *begin, uint64_t *end)
+{
+    if (world < 1 || rank < 0 || rank >= world || !begin || !end)
+        return DST_ERR_ARG;
+    const SharedLayout lay = shared_layout(n, world, 0);
+    *begin = std::min<uint64_t>(n, (uint64_t)rank * lay.rmax);
+    *end = std::min<uint64_t>(n, ((uint64_t)rank + 1) * lay.rmax);
     return DST_OK;
 }
 

@@ -95,6 +95,7 @@ struct RecordIndex {              // per record: the sites where it differs from
     uint64_t ref_epoch = 0;
     bool without_hot = false;         // hybrid path: the hot sites are left out
     bool valid = false;
+    bool ranges_valid = false;        // range_start holds the marks of THESE lists (a column set's site buckets can be built from them)
 };
 
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
@@ -116,6 +117,10 @@ struct DeviceSet {
     size_t n = 0, len = 0, nchunks = 0, npad = 0;
     bool loaded = false;
     bool have_counts = false;
+    // dst_upload_shared: only the planes of records [part_begin, part_end) are this rank's own work and valid; the lists
+    // of ALL records came by the exchange.  Such a set runs on the consensus path only.
+    bool partial = false;
+    size_t part_begin = 0, part_end = 0;
     bool lean = false;            // only the four base planes are stored (a low-diversity set headed for the consensus path):
                                   // the dense pair kernels' other planes are derived on demand (ensure_derived)
     uint64_t epoch = 0;           // bumped by every upload: stale consensus indexes are rebuilt
@@ -200,7 +205,22 @@ struct ConsensusLaunch {
                                  // 2: more than one event per pair — every wave in both roles (consensus_pair_kernel)
 };
 
+// ---- shared preparation (dst_shared.cpp): one rank's exchange block, in 32-bit words ------------------
+//   [0] entries of the block's lists   [1] 1: they did not fit ent_cap   [2, 3] first invalid byte (~0: none)   [4..15] 0
+//   [cnt_at .. + rmax)        list lengths of the rank's records (record k * rmax + i of the set)
+//   [counts_at .. + 4 rmax)   their {A,T,G,C} counts
+//   [ent_at .. + ent_cap)     the entries, record after record
+struct SharedLayout {
+    uint32_t world, rmax, cnt_at, counts_at, ent_at, ent_cap, words;
+};
+SharedLayout shared_layout(uint64_t n, int world, uint32_t ent_cap);   // dst_host.cpp (pure host)
+
 // ---- consensus-path launchers (dst_consensus.hip) --------------------------------------------
+hipError_t launch_shared_block(uint32_t *block, const SharedLayout &lay, const DeviceSet &set, size_t rec_begin, size_t count,
+                               const uint32_t *off_local, const unsigned long long *first_bad, hipStream_t stream);
+// the gathered blocks -> set.rec.off / ent / range_start (and set.counts), then the report for the host (kReportWords + 1 words)
+hipError_t launch_shared_splice(const uint32_t *gathered, const SharedLayout &lay, DeviceSet &set, uint32_t *len_all,
+                                uint32_t *scan_tmp, bool with_counts, unsigned long long *report, hipStream_t stream);
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
 // the same from the row-major code matrix (before the pack)
 hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream);
@@ -213,8 +233,11 @@ hipError_t launch_index(const DeviceSet &set, const uint4 *ref_planes, const uin
                         uint32_t *rec_off_or_cnt, uint32_t *rec_ent, unsigned long long *total,
                         hipStream_t stream, uint32_t *range_start = nullptr);
 // the same lists from the pack's slots (set.rec.pre_slots) instead of the planes; without_hot: leave the hot entries out
+// rec_begin / rec_end / ent_cap: only those records (rec_off[0] = record rec_begin's offset), entries at or beyond ent_cap
+// dropped — one rank's share of a set, written into an exchange block of fixed size (dst_upload_shared)
 hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, bool without_hot,
-                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream);
+                            uint32_t *rec_off, uint32_t *rec_ent, uint32_t *range_start, hipStream_t stream, size_t rec_begin = 0,
+                            size_t rec_end = ~(size_t)0, uint32_t ent_cap = 0xFFFFFFFFu);
 // a column set's site buckets from its lists (set.rec -> set.site); *ovf_total (zeroed by the caller) counts the
 // overflow entries placed in set.site.ent
 hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t *ovf_total, hipStream_t stream);
@@ -243,9 +266,13 @@ struct PackLists {
     uint32_t *cnt_cold, *cnt_hot;              // [n], zeroed
     uint4 *slots;                              // [nchunks][npad] the differences of every (record, chunk), see pack_kernel
 };
+// rec_begin / rec_end: only those records are packed (one rank's share of a set: dst_upload_shared)
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
-                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream);
+                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream, size_t rec_begin = 0,
+                       size_t rec_end = ~(size_t)0);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
+// the counts of records [rec_begin, rec_end) only, out[0..4) = record rec_begin's
+hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream);
 hipError_t launch_derive(const DeviceSet &set, hipStream_t stream);   // planes K, X1, X0, CL of a lean set from its base planes
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
 hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,

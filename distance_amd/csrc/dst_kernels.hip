@@ -18,6 +18,8 @@
 // in VGPRs for the whole sweep over L.  Tiles of one column panel are dealt to workgroups that
 // share an XCD so the panel is served by that XCD's L2.  The kernel runs at the measured issue
 // ceiling of its instruction mix (tools/ubench/ifetch.hip, order.hip).
+#include <algorithm>
+
 #include "dst_device.hpp"
 
 namespace dst {
@@ -65,11 +67,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                                                    uint32_t nchunks, uint32_t npad,
                                                    uint4 *__restrict__ planes,
                                                    unsigned long long *__restrict__ first_bad,
-                                                   int aligned16, PackLists lists)
+                                                   int aligned16, PackLists lists, uint32_t rec_first, uint32_t rec_last)
 {
-    const uint32_t s = blockIdx.y * blockDim.x + threadIdx.x;
+    // records [rec_first, rec_last): the whole padded set, or one rank's share of it (dst_upload_shared)
+    const uint32_t s = rec_first + blockIdx.y * blockDim.x + threadIdx.x;
     const uint32_t c = blockIdx.x;
-    if (s >= npad)
+    if (s >= rec_last)
         return;
     uint32_t out[PL_COUNT][4];
 #pragma unroll
@@ -245,10 +248,11 @@ __global__ __launch_bounds__(256) void derive_kernel(uint4 *__restrict__ planes,
 // {A,T,G,C} counts by code (src/fastaio.rs:53-66): a known base is K & its own bit-plane.
 __global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ planes,
                                                      uint32_t nchunks, uint32_t npad,
-                                                     uint32_t *__restrict__ counts)
+                                                     uint32_t *__restrict__ counts, uint32_t rec_first, uint32_t rec_last)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= npad)
+    // counts[0] is record rec_first's (the whole padded set, or one rank's share of it)
+    const uint32_t s = rec_first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= rec_last)
         return;
     uint32_t a = 0, t = 0, g = 0, cc = 0;
     const size_t ps = (size_t)nchunks * npad;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ p
         cc += __builtin_popcount(K.x & C.x) + __builtin_popcount(K.y & C.y) +
               __builtin_popcount(K.z & C.z) + __builtin_popcount(K.w & C.w);
     }
-    reinterpret_cast<uint4 *>(counts)[s] = make_uint4(a, t, g, cc);
+    reinterpret_cast<uint4 *>(counts)[s - rec_first] = make_uint4(a, t, g, cc);
 }
 
 // =============================================================================================
@@ -651,16 +655,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tal
 // launchers
 // =============================================================================================
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
-                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream)
+                       unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream, size_t rec_begin, size_t rec_end)
 {
+    // the records of one rank's share; the rank that holds the set's last record also writes the padding records (all N)
+    const uint32_t first = (uint32_t)std::min(rec_begin, set.npad);
+    const uint32_t last = (uint32_t)(rec_end >= set.n ? set.npad : rec_end);
+    if (last <= first)
+        return hipSuccess;
     const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
                           (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);
-    dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
+    dim3 grid((unsigned)set.nchunks, (unsigned)((last - first + 255) / 256));
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
-                       d_first_bad, aligned16, lists ? *lists : none);
+                       d_first_bad, aligned16, lists ? *lists : none, first, last);
     return hipGetLastError();
 }
 
@@ -674,7 +683,16 @@ hipError_t launch_derive(const DeviceSet &set, hipStream_t stream)
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream)
 {
     hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((set.npad + 255) / 256)), dim3(256), 0, stream,
-                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, set.counts);
+                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, set.counts, 0u, (uint32_t)set.npad);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream)
+{
+    if (rec_end <= rec_begin)
+        return hipSuccess;
+    hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((rec_end - rec_begin + 255) / 256)), dim3(256), 0, stream,
+                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, out, (uint32_t)rec_begin, (uint32_t)rec_end);
     return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import SLAB_SINK, DistanceError, load
+from ._lib import ALLGATHER_FN, SLAB_SINK, DistanceError, load
 
 MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
@@ -56,6 +56,15 @@ def partition_rect(n_rows: int, parts: int) -> list[int]:
     if rc:
         raise DistanceError(rc, "dst_partition_rect")
     return [int(x) for x in b]
+
+
+def shared_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """The records rank `rank` of `world` packs and lists in a shared upload (dst_shared_range)."""
+    b, e = C.c_uint64(), C.c_uint64()
+    rc = load().dst_shared_range(n, rank, world, C.byref(b), C.byref(e))
+    if rc:
+        raise DistanceError(rc, "dst_shared_range")
+    return int(b.value), int(e.value)
 
 
 def plan_tiles(square: bool, row_begin: int, row_end: int, n_cols: int, measure, variant: int = 0):
@@ -193,6 +202,17 @@ class Engine:
                       d_counts_ptr: int | None = None, stream: int | None = None):
         self._check(self._lib.dst_upload_device(self._h, slot, d_ptr, n, length, row_stride, d_counts_ptr,
                                                 stream))
+
+    def upload_shared(self, comm: "Comm", slot: int, d_ptr: int, n: int, length: int, row_stride: int,
+                      with_counts: bool = False, stream: int | None = None):
+        """Collective: this rank packs and lists its share of the records, one all-gather brings everybody's lists
+        (dst_upload_shared)."""
+        self._check(self._lib.dst_upload_shared(comm._h, slot, d_ptr, n, length, row_stride, int(with_counts), stream))
+
+    def shared_stats(self, slot: int = 0) -> dict:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.dst_shared_stats(self._h, slot, C.byref(a), C.byref(b), C.byref(c)))
+        return {"shared_uploads": int(a.value), "fallbacks": int(b.value), "block_entries": int(c.value)}
 
     def set_info(self, slot: int) -> tuple[int, int]:
         n, length = C.c_size_t(), C.c_size_t()
@@ -332,6 +352,60 @@ class Engine:
     def out_bytes(self, measure, pairs: int, tallies: bool = False) -> int:
         return int(self._lib.dst_out_bytes(_measure_id(measure), OUT_TALLY if tallies else OUT_DISTANCE,
                                            pairs))
+
+
+class Comm:
+    """dst_comm: the ranks of a multi-GPU job (one process — or, in tests, one thread — per rank).
+
+    Comm.rccl(eng, id_bytes, rank, world): RCCL inside the library (dst_comm_create); `id_bytes` comes from
+    Comm.unique_id() on rank 0 and travels by the launcher's own means.
+    Comm.custom(eng, rank, world, allgather): the caller's transport — allgather(d_send, d_recv, bytes_per_rank, stream)
+    with raw device pointers (dst_comm_create_custom)."""
+
+    def __init__(self, eng: Engine, handle, keep=None):
+        self._eng, self._lib, self._h, self._keep = eng, eng._lib, handle, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = load().dst_comm_unique_id(buf, 128)
+        if rc:
+            raise DistanceError(rc, "dst_comm_unique_id (RCCL not available?)")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, eng: Engine, id_bytes: bytes, rank: int, world: int) -> "Comm":
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        eng._check(eng._lib.dst_comm_create(eng._h, buf, rank, world, C.byref(h)))
+        return cls(eng, h)
+
+    @classmethod
+    def custom(cls, eng: Engine, rank: int, world: int, allgather) -> "Comm":
+        def _cb(_user, d_send, d_recv, nbytes, stream):
+            try:
+                allgather(d_send, d_recv, int(nbytes), stream)
+                return 0
+            except Exception as exc:   # an exception must not cross the C frames
+                import traceback
+                traceback.print_exception(exc)
+                return 1
+
+        cb = ALLGATHER_FN(_cb)
+        h = C.c_void_p()
+        eng._check(eng._lib.dst_comm_create_custom(eng._h, rank, world, cb, None, C.byref(h)))
+        return cls(eng, h, keep=cb)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dst_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class Stream:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DST_ABI_VERSION 2
+#define DST_ABI_VERSION 3
 
 typedef struct dst_ctx dst_ctx;
 
@@ -214,6 +214,12 @@ int dst_stream_close(dst_stream *stream);
 typedef struct dst_comm dst_comm;
 int dst_comm_unique_id(uint8_t *id, size_t cap);
 int dst_comm_create(dst_ctx *ctx, const uint8_t *id, int rank, int world, dst_comm **comm);
+/* A communicator over the caller's own transport (MPI, a test harness): `allgather` must take `bytes_per_rank` bytes at
+ * d_send on every rank and leave rank r's at d_recv + r * bytes_per_rank on every rank (device memory), ordered after
+ * the work already queued on `stream` (hipStream_t) and visible to work queued on it afterwards; 0 = ok.  Serves
+ * dst_upload_shared; dst_gather_slabs needs an RCCL communicator. */
+typedef int (*dst_allgather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int dst_comm_create_custom(dst_ctx *ctx, int rank, int world, dst_allgather_fn allgather, void *user, dst_comm **comm);
 int dst_comm_destroy(dst_comm *comm);
 int dst_comm_info(const dst_comm *comm, int *rank, int *world);
 /* Collective.  byte_offsets / byte_sizes have `world` entries and are the same on every rank: rank r contributes
@@ -225,6 +231,27 @@ int dst_comm_info(const dst_comm *comm, int *rank, int *world);
  * NULL = the context's stream, then the call waits). */
 int dst_gather_slabs(dst_comm *comm, const void *d_local, void *d_full, const uint64_t *byte_offsets,
                      const uint64_t *byte_sizes, int root, void *stream);
+
+/* ---- multi-GPU: the preparation of a loaded set shared out over the ranks ------------------------------------ */
+/* Collective form of dst_upload_device for slot 0 against itself (one file, the square job): instead of every rank
+ * packing and indexing the whole set before it computes its row range — the reference's workers all read the ONE
+ * prepared copy of loaded_fastas, src/lib.rs:413-458, 219-242 — rank k packs and lists records
+ * [begin, end) = dst_shared_range(n, k, world) only, one all-gather brings every rank's difference lists (and base
+ * counts, with_counts != 0: needed by tn93) to every rank, and the site tables and per-record constants are built from the
+ * lists locally.  d_codes is the WHOLE n x len matrix in this GPU's memory (the call reads the rank's own records and the
+ * 512 records every rank samples the reference sequence from).  Afterwards dst_run_square / dst_text_square work for any
+ * row range on the consensus path; the dense and hybrid kernels, dst_consensus and dst_differences need every record's
+ * planes and refuse such a set (DST_ERR_STATE).  When the lists cannot serve (a context forced dense, a set too
+ * diverse, hot columns, lists larger than the exchange blocks — every rank reads that from the same figures) the call
+ * IS dst_upload_device on every rank.  Every rank must pass the same n, len, with_counts, the same data and hold the
+ * same dst_set_path / dst_set_prep_threshold settings.  Synchronous like dst_upload_device (validity check). */
+int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes, size_t n, size_t len, size_t row_stride,
+                      int with_counts, void *stream);
+/* the records rank `rank` of `world` prepares (pure host code) */
+int dst_shared_range(uint64_t n, int rank, int world, uint64_t *begin, uint64_t *end);
+/* how dst_upload_shared went on this context so far: uploads that were shared, uploads that fell back to the replicated
+ * form, entries of the largest exchange block of the last one (any pointer may be NULL) */
+int dst_shared_stats(const dst_ctx *ctx, int slot, uint64_t *shared_uploads, uint64_t *fallbacks, uint64_t *block_entries);
 
 /* In-order sink (the shape of gather_write's input, src/lib.rs:612-644): the run is cut into row
  * slabs of at most max_pairs pairs (>= one row each) and `sink` is called once per slab, strictly

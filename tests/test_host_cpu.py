@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/distance_hip.h but not exported"
-    assert lib.dst_abi_version() == 2
+    assert lib.dst_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
