@@ -12,7 +12,14 @@ Prints ONE JSON line (rank 0).  `value` = pairs of the whole job / step time, on
 path choice (DST_PATH_AUTO); the line also carries, each timed over the same steps/warmup:
   legs.dense      the same measure with the dense bit-plane kernels forced (VALU-issue roofline),
   legs.tn93*      the C3 measure (the metric is "raw+tn93"), default path and dense,
+  legs.clades / legs.nruns   (N = 1) the same shape with phylogenetic structure (a third of the records share 2 % of the
+                  sites) and with 5 % of the records half N: the consensus path's time depends on the data,
+  verify          ALWAYS: the default leg's results against the dense leg's bit for bit, rows against the oracle,
   cpu_baseline(s) the oracle on the host cores for raw / tn93 / n_high / n (sparse walk) and the C1 line.
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as a child process,
+before this process touches a GPU).  N > 1: the preparation of the set is shared out over the ranks (dst_upload_shared:
+every rank packs and lists 1/N of the records, one RCCL all-gather of the lists), every rank computes a contiguous row
+range of equal pair count.
 
 Default workload: 50,000 x 30,000, -m raw — the shape the north-star target is quoted on.
 Synthetic data: SURVEY §8(d)'s generator (tools/synth: xoshiro256**, seed 0xD157A2CE ^ config id).
@@ -23,12 +30,36 @@ import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def _launch_ranks_if_needed():
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD process tree and relay its
+    exit code.  This runs before torch / the HIP library are imported: the parent never touches a GPU."""
+    if "WORLD_SIZE" in os.environ or "--gpus" not in " ".join(sys.argv):
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args()[0].gpus
+    if n <= 1:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+if __name__ == "__main__":
+    _launch_ranks_if_needed()
 
 import numpy as np
 import torch
@@ -158,7 +189,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="debug: N ranks share GPU 0 and exchange over gloo via host staging (checks the "
                          "multi-rank indexing on a 1-GPU box; RCCL itself needs one GPU per rank)")
-    ap.add_argument("--verify", action="store_true", help="rank 0 re-computes sampled rows and compares (always on for N>1)")
+    ap.add_argument("--verify", action="store_true", help="(kept for old command lines: verification is always on)")
     ap.add_argument("--wire-f64", action="store_true", help="N>1: always send 8-byte results, never uint16 tallies")
     ap.add_argument("--batch", type=int, default=64, help="C4: streamed records per batch")
     ap.add_argument("--batches", type=int, default=8, help="C4: streamed batches per step")
@@ -168,10 +199,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    flags = da.load().dst_build_flags().decode()
+    if flags:
+        raise SystemExit(f"libdistance_hip.so is a measurement build ({flags}): bench.py times production builds only")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     dev_index = 0 if args.rehearse_gloo else local_rank
@@ -202,6 +233,7 @@ def main():
     assert stream != 0
     host_codes = synth.alignment(args.seed ^ config_id, n, L, threads=host_threads())   # every rank: the full set
     codes = torch.from_numpy(host_codes).to(dev)
+    host_codes_full = host_codes            # rank 0's oracle rows read it (all ranks generate the same set)
     if rank != 0 or args.no_cpu_baseline:
         host_codes = host_codes[:1]
     eng = da.Engine(dev_index)
@@ -218,11 +250,13 @@ def main():
     # ---------------------------------------------------------------------------------------------
     # N = 1: one engine, the whole triangle per step
     # ---------------------------------------------------------------------------------------------
-    def single_gpu_leg(m: str, path: str, out: torch.Tensor) -> dict:
+    def single_gpu_leg(m: str, path: str, out: torch.Tensor, data: torch.Tensor | None = None, steps: int | None = None) -> dict:
         eng.set_path(path)
+        data = codes if data is None else data
+        steps = args.steps if steps is None else steps
 
         def step():
-            eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+            eng.upload_device(0, data.data_ptr(), n, L, data.stride(0), None, stream)
             eng.run_square_device(m, 0, n, out.data_ptr(), out.numel() * 8, stream=stream)
 
         for _ in range(args.warmup):
@@ -230,7 +264,7 @@ def main():
         fence()
         pair_ms, pack_ms = [], []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
             ms = eng.last_kernel_ms()     # HIP events recorded on the launch stream
             pair_ms.append(ms["pair_ms"])
@@ -239,12 +273,41 @@ def main():
         elapsed = time.perf_counter() - t0
         used = eng.last_path()
         k_ms = float(np.mean(pair_ms))
-        leg = {"measure": m, "path_requested": path, "path_used": used, "ms_per_step": 1e3 * elapsed / args.steps,
-               "pairs_per_s": total_pairs / (elapsed / args.steps), "steps": args.steps, "warmup": args.warmup,
+        leg = {"measure": m, "path_requested": path, "path_used": used, "ms_per_step": 1e3 * elapsed / steps,
+               "pairs_per_s": total_pairs / (elapsed / steps), "steps": steps, "warmup": args.warmup,
                "kernels_ms": {"pack": float(np.mean(pack_ms)), "pair": k_ms,
-                              "lists_and_constants": max(0.0, 1e3 * elapsed / args.steps - k_ms - float(np.mean(pack_ms)))}}
+                              "lists_and_constants": max(0.0, 1e3 * elapsed / steps - k_ms - float(np.mean(pack_ms)))}}
         leg["roofline"] = roofline(m, used, k_ms, total_pairs)
+        # the whole step against the same roofline: what it must move through HBM at the least (the byte matrix read
+        # once, the bit-planes written once, the results written once) over the time of a step
+        step_bytes = n * L + n * ((L + 127) // 128) * 64 + total_pairs * 8
+        leg["whole_step"] = {"bound": "hbm", "achieved": step_bytes / (elapsed / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": step_bytes,
+                             "note": "byte matrix read once + four base bit-planes written once + 8 B per pair written once, "
+                                     "over the wall time of a step (pack, lists, tables, pair kernel, launch gaps and the upload's wait)"}
         return leg
+
+    def bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
+        return bool(torch.equal(a.view(torch.int64), b.view(torch.int64)))
+
+    def oracle_rows(out: torch.Tensor, m: str, data_host: np.ndarray, rows) -> dict:
+        """rows of the job's result against the oracle (restated reference algorithm, libm): integers and raw bit-exact
+        (raw is one IEEE division of exact integers), jc69 / k80 / tn93 within 1e-12 (BASELINE.json's tolerance)"""
+        import oracle
+        bad, worst = 0, 0.0
+        for row in rows:
+            lo, hi = da.square_row_start(n, row), da.square_row_start(n, row + 1)
+            want = oracle.all_pairs_square(m, data_host, threads=host_threads(), pair_range=(lo, hi))
+            got = out[lo:hi].cpu().numpy().astype(np.float64)
+            if m in da.INT_MEASURES or m == "raw":
+                ok = np.array_equal(got, want, equal_nan=True)
+            else:
+                same = (got == want) | (np.isnan(got) & np.isnan(want))
+                err = np.abs(np.where(same, 0.0, got - want))
+                worst = max(worst, float(np.nanmax(err)) if len(err) else 0.0)
+                ok = bool(np.all(same | (err <= 1e-12)))
+            bad += int(not ok)
+        return {"rows_checked": len(rows), "rows_bad": bad, "max_abs_err": worst}
 
     def roofline(m: str, used: str, k_ms: float, launch_pairs: int) -> dict:
         words = (L + 127) // 128 * 4
@@ -301,16 +364,56 @@ def main():
 
     if world == 1:
         full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
+        check_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)   # the dense path's results, for verify
         legs = {}
+        verify = {"against": "the dense bit-plane path on the same inputs, every result bit for bit (torch.equal on the int64 "
+                             "views), and sampled rows against the oracle (restated reference algorithm with libm)"}
+        sample_rows = sorted({r for r in (0, n // 2, n - 2) if 0 <= r < n - 1})
         main_leg = single_gpu_leg(measure, args.path, full_out)
+        if main_leg["path_used"] != "dense":
+            if not args.no_extra:
+                legs["dense"] = single_gpu_leg(measure, "dense", check_out)
+            else:   # still verify: one untimed dense run
+                eng.set_path("dense")
+                eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
+                eng.run_square_device(measure, 0, n, check_out.data_ptr(), check_out.numel() * 8, stream=stream)
+                torch.cuda.synchronize()
+            verify["default_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+        verify["oracle_" + measure] = oracle_rows(full_out, measure, host_codes_full, sample_rows)
         if not args.no_extra:
-            if main_leg["path_used"] != "dense":
-                legs["dense"] = single_gpu_leg(measure, "dense", full_out)
             if stock and args.workload == "C3raw":
                 legs["tn93"] = single_gpu_leg("tn93", args.path, full_out)
+                verify["oracle_tn93"] = oracle_rows(full_out, "tn93", host_codes_full, sample_rows[:2])
                 if legs["tn93"]["path_used"] != "dense":
-                    legs["tn93_dense"] = single_gpu_leg("tn93", "dense", full_out)
+                    legs["tn93_dense"] = single_gpu_leg("tn93", "dense", check_out)
+                    # device-finalised f64 of two kernels: the same tallies through the same finalisation code
+                    verify["tn93_default_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+                # ---- the same shape, other data: the consensus path's time depends on the alignment
+                root_codes = synth.root(args.seed ^ config_id, L)
+                variants = {
+                    "clades": ("a third of the records share the same substitution at 2 % of the sites (clade-defining "
+                               "mutations): tools/synth clade_plan",
+                               lambda t: synth.apply_clades(t, root_codes, *synth.clade_plan(args.seed ^ config_id, n, L))),
+                    "nruns": ("5 % of the records carry 1-3 runs of N over half of their sites (failed amplicons): "
+                              "tools/synth nrun_plan",
+                              lambda t: synth.apply_nruns(t, synth.nrun_plan(args.seed ^ config_id, n, L))),
+                }
+                for name, (what, apply) in variants.items():
+                    var = apply(codes.clone())
+                    torch.cuda.synchronize()
+                    leg = single_gpu_leg(measure, args.path, full_out, data=var, steps=max(3, args.steps // 2))
+                    leg["data"] = what
+                    eng.set_path("dense")
+                    eng.upload_device(0, var.data_ptr(), n, L, var.stride(0), None, stream)
+                    eng.run_square_device(measure, 0, n, check_out.data_ptr(), check_out.numel() * 8, stream=stream)
+                    torch.cuda.synchronize()
+                    leg["dense_ms"] = eng.last_kernel_ms()["pair_ms"]
+                    verify[name + "_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+                    legs[name] = leg
+                    del var
             eng.set_path(args.path)
+        verify["ok"] = all(v for k, v in verify.items() if k.endswith("bits_equal")) and \
+            all(v["rows_bad"] == 0 for k, v in verify.items() if k.startswith("oracle_"))
         result = {
             "metric": "pairwise comparisons/sec",
             "value": main_leg["pairs_per_s"],
@@ -330,18 +433,19 @@ def main():
                        "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
                        "variant": args.variant},
             "roofline": main_leg["roofline"],
+            "whole_step": main_leg["whole_step"],
             "kernels_ms": main_leg["kernels_ms"],
             "site_compares_per_s": main_leg["pairs_per_s"] * L,
             "legs": legs,
+            "verify": verify,
         }
-        if args.verify:
-            result["verify"] = verify_rows(eng, codes, full_out, n, L, measure, [0, 1, n // 3, n // 2, n - 2], dev_index, stream)
         if not args.no_cpu_baseline:
             base, others = cpu_baselines(host_codes[:min(n, 8000)], measure)
             result["cpu_baseline"] = base
             result["cpu_baselines"] = others
         print(json.dumps(result))
         eng.close()
+        assert verify["ok"], "the timed results differ from the dense path or the oracle"
         return
 
     # ---------------------------------------------------------------------------------------------
@@ -351,74 +455,90 @@ def main():
     # writes a contiguous range of the canonical order.  That is how the CLI runs N GPUs (one context, one D2H stream
     # and one formatter pipeline per GPU; the ordered writer takes the slabs in rank order).
     if args.exchange == "none":
-        # A rank that starts at row r0 pairs its rows with records r0.. only, so it uploads (packs, indexes) records
-        # [r0, n) as a set of their own: row i of the sub-triangle is row r0 + i of the whole one, pair for pair.  The
-        # per-record preparation is what does not shrink with N, so the row ranges are cut to make
-        # prep x (records a rank holds) + pair time x (its pairs) equal over the ranks, from a timed probe.
-        def run_range(r0, r1, out):
-            if r1 <= r0 or r0 >= n - 1:
-                return                      # no rows (or only the last record, which has no pair of its own)
-            sub = codes[r0:]
-            eng.upload_device(0, sub.data_ptr(), n - r0, L, codes.stride(0), None, stream)
-            eng.run_square_device(measure, 0, r1 - r0, out.data_ptr(), out.numel() * 8, stream=stream)
-
-        eq_bounds, eq_offs = slab_layout(n, world, square=True)
-        probe_out = torch.empty(max(eq_offs[rank + 1] - eq_offs[rank], 1), dtype=out_dtype, device=dev)
-        t_all = 0.0
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_range(eq_bounds[rank], eq_bounds[rank + 1], probe_out)
-            torch.cuda.synchronize()
-            t_all = time.perf_counter() - t0
-        pair_s = eng.last_kernel_ms()["pair_ms"] * 1e-3
-        held, mine = n - eq_bounds[rank], max(eq_offs[rank + 1] - eq_offs[rank], 1)
-        tt = torch.tensor([max(t_all - pair_s, 0.0) / held, pair_s / mine], dtype=torch.float64,
-                          device=dev if not args.rehearse_gloo else "cpu")
-        dist.all_reduce(tt)
-        prep_per_record, s_per_pair = float(tt[0].item()) / world, float(tt[1].item()) / world
-        del probe_out
-        bounds = balanced_bounds(n, world, prep_per_record, s_per_pair)
-        offsets = [da.square_row_start(n, b) for b in bounds]
+        # Default path: the PREPARATION is shared out too (dst_upload_shared): rank k packs and lists records
+        # [k rmax, (k+1) rmax), one all-gather (RCCL inside the library) brings every rank's difference lists to all,
+        # every rank builds the site tables and constants from the lists and computes its rows of the whole triangle.
+        # Dense leg: no lists to share — a rank that starts at row r0 pairs its rows with records r0.. only, so it packs
+        # records [r0, n) as a set of their own (row i of that sub-triangle is row r0 + i of the whole one).
+        comm, transport = make_comm(eng, rank, world, dev, args.rehearse_gloo, work_stream)
+        bounds, offsets = slab_layout(n, world, square=True)
         r0, r1 = bounds[rank], bounds[rank + 1]
         my_pairs = offsets[rank + 1] - offsets[rank]
         local_out = torch.empty(max(my_pairs, 1), dtype=out_dtype, device=dev)
+        cpu_or_dev = dev if not args.rehearse_gloo else "cpu"
 
-        def step():
-            run_range(r0, r1, local_out)
+        def shared_step(m):
+            eng.upload_shared(comm, 0, codes.data_ptr(), n, L, codes.stride(0), with_counts=(m == "tn93"), stream=stream)
+            if r1 > r0 and r0 < n - 1:
+                eng.run_square_device(m, r0, r1, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
 
-        for _ in range(args.warmup):
-            step()
-        fence()
-        pair_ms, pack_ms = [], []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            ms = eng.last_kernel_ms()
-            pair_ms.append(ms["pair_ms"])
-            pack_ms.append(ms["pack_ms"])
-        fence()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not args.rehearse_gloo else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        used = eng.last_path()
-        # every rank checks rows of ITS slab against a fresh single-engine dense run; the counts meet on rank 0
-        rows = sorted({r for r in (r0, (r0 + r1) // 2, r1 - 1) if r0 <= r < min(r1, n - 1)})
-        check = verify_rows(eng, codes, local_out, n, L, measure, rows, dev_index, stream, first_row=r0) if rows else \
-            {"rows_checked": 0, "rows_bad": 0}
-        v = torch.tensor([check["rows_checked"], check["rows_bad"]], dtype=torch.int64, device=dev if not args.rehearse_gloo else "cpu")
-        dist.all_reduce(v)
-        if rank == 0:
+        def dense_step(m):
+            if r1 > r0 and r0 < n - 1:
+                sub = codes[r0:]
+                eng.upload_device(0, sub.data_ptr(), n - r0, L, codes.stride(0), None, stream)
+                eng.run_square_device(m, 0, r1 - r0, local_out.data_ptr(), local_out.numel() * 8, stream=stream)
+
+        def multi_leg(m: str, path: str) -> dict:
+            eng.set_path(path)
+            step = (lambda: dense_step(m)) if path == "dense" else (lambda: shared_step(m))
+            for _ in range(args.warmup):
+                step()
+            fence()
+            pair_ms, pack_ms = [], []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                ms = eng.last_kernel_ms()
+                pair_ms.append(ms["pair_ms"])
+                pack_ms.append(ms["pack_ms"])
+            fence()
+            elapsed = time.perf_counter() - t0
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            used = eng.last_path()
+            # every rank checks rows of ITS slab against a fresh single-engine dense run; the counts meet on rank 0
+            rows = sorted({r for r in (r0, (r0 + r1) // 2, r1 - 1) if r0 <= r < min(r1, n - 1)})
+            check = verify_rows(eng, codes, local_out, n, L, m, rows, dev_index, stream, first_row=r0) if rows else \
+                {"rows_checked": 0, "rows_bad": 0}
+            v = torch.tensor([check["rows_checked"], check["rows_bad"]], dtype=torch.int64, device=cpu_or_dev)
+            dist.all_reduce(v)
             k_ms = float(np.mean(pair_ms))
+            st = eng.shared_stats()
+            leg = {"measure": m, "path_requested": path, "path_used": used, "ms_per_step": 1e3 * elapsed / args.steps,
+                   "pairs_per_s": total_pairs / (elapsed / args.steps), "steps": args.steps, "warmup": args.warmup,
+                   "kernels_ms": {"rank": 0, "pack": float(np.mean(pack_ms)), "pair": k_ms,
+                                  "lists_exchange_and_constants": max(0.0, 1e3 * elapsed / args.steps - k_ms - float(np.mean(pack_ms)))},
+                   "roofline": roofline(m, used, k_ms, my_pairs),
+                   "preparation": ("shared: every rank packs and lists 1/N of the records, one all-gather of the lists "
+                                   f"({st['block_entries']} entries in the largest block; {st['shared_uploads']} shared uploads, "
+                                   f"{st['fallbacks']} replicated fall-backs so far)") if path != "dense" else
+                                  "replicated: every rank packs the records from its first row on",
+                   "verify": {"rows_checked": int(v[0].item()), "rows_bad": int(v[1].item()),
+                              "against": "single-engine dense-path run of the same rows, on every rank"}}
+            return leg
+
+        main_leg = multi_leg(measure, args.path)
+        legs = {}
+        oracle_check = None
+        if rank == 0 and r1 > r0:
+            # rank 0's slab starts at row 0: its first rows against the oracle
+            oracle_check = oracle_rows(local_out, measure, host_codes_full, [0, min(r1 - 1, n - 2)])
+        if not args.no_extra:
+            if main_leg["path_used"] != "dense":
+                legs["dense"] = multi_leg(measure, "dense")
+            if stock and args.workload == "C3raw":
+                legs["tn93"] = multi_leg("tn93", args.path)
+        bad_rows = main_leg["verify"]["rows_bad"] + sum(l["verify"]["rows_bad"] for l in legs.values())
+        if rank == 0:
             result = {
                 "metric": "pairwise comparisons/sec",
-                "value": total_pairs / (elapsed / args.steps),
+                "value": main_leg["pairs_per_s"],
                 "unit": "pairs/s",
                 "n_gpus": world,
                 "steps": args.steps,
                 "warmup": args.warmup,
-                "ms_per_step": 1e3 * elapsed / args.steps,
+                "ms_per_step": main_leg["ms_per_step"],
                 "higher_is_better": True,
                 "scaling": "strong",
                 "vs_baseline": None,
@@ -426,27 +546,28 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"{n} x {L} all-pairs, -m {measure} (i<j, f64 distances in canonical order, "
                                        f"{world} contiguous ranges, each in its rank's HBM)",
-                           "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs, "path": used,
-                           "partition": f"{world} contiguous row ranges, rows {bounds}: cut so that preparation x records held "
-                                        f"({prep_per_record * 1e9:.1f} ns per record, measured) + pair time x pairs "
-                                        f"({s_per_pair * 1e12:.2f} ps per pair, measured) is equal over the ranks; a rank uploads only "
-                                        "the records from its first row on; no collective in the data path "
-                                        "(--exchange gather adds the RCCL send/recv of every slab to rank 0)",
+                           "name": args.workload, "n": n, "len": L, "measure": measure, "pairs": total_pairs,
+                           "path": main_leg["path_used"],
+                           "partition": f"{world} contiguous row ranges of equal pair count, rows {bounds}; no collective on the results "
+                                        "(--exchange gather adds the RCCL send/recv of every slab to rank 0); the preparation's one "
+                                        f"all-gather of difference lists runs over {transport}",
                            "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ {config_id}",
-                           "note": "strong scaling of a step whose per-rank share of the pairs shrinks with N while the rank that "
-                                   "owns row 0 still packs and indexes the WHOLE set each step (kernels_ms.pack + "
-                                   "lists_and_constants): that part bounds the speed-up (DESIGN.md 6)",
+                           "note": "strong scaling of a 3 ms one-GPU step: what does not divide by N is the reference sample, the "
+                                   "exchange and the site tables (DESIGN.md 6); legs.dense is the same job on the dense kernels, "
+                                   "whose 190 ms divide by N",
                            "variant": args.variant},
-                "roofline": roofline(measure, used, k_ms, my_pairs),
-                "kernels_ms": {"rank": 0, "pack": float(np.mean(pack_ms)), "pair": k_ms,
-                               "lists_and_constants": max(0.0, 1e3 * elapsed / args.steps - k_ms - float(np.mean(pack_ms)))},
-                "site_compares_per_s": total_pairs / (elapsed / args.steps) * L,
-                "verify": {"rows_checked": int(v[0].item()), "rows_bad": int(v[1].item()),
-                           "against": "single-engine dense-path run of the same rows, on every rank"},
+                "roofline": main_leg["roofline"],
+                "kernels_ms": main_leg["kernels_ms"],
+                "preparation": main_leg["preparation"],
+                "site_compares_per_s": main_leg["pairs_per_s"] * L,
+                "legs": legs,
+                "verify": dict(main_leg["verify"], oracle=oracle_check),
             }
             print(json.dumps(result))
-        assert int(v[1].item()) == 0, "a rank's slab differs from a single-engine dense run"
+        assert bad_rows == 0, "a rank's slab differs from a single-engine dense run"
+        assert oracle_check is None or oracle_check["rows_bad"] == 0, "rank 0's rows differ from the oracle"
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
         eng.close()
         return
@@ -630,41 +751,55 @@ def main():
     eng.close()
 
 
-def balanced_bounds(n: int, world: int, prep_per_record: float, s_per_pair: float) -> list[int]:
-    """Row bounds b[0] = 0 .. b[world] = n with prep_per_record * (n - b[k]) + s_per_pair * pairs(rows b[k]..b[k+1])
-    equal over the ranks (bisection on the common time; a rank holds the records from its first row on)."""
-    total = n * (n - 1) // 2
+def make_comm(eng, rank: int, world: int, dev, rehearse: bool, work_stream):
+    """The communicator of the shared preparation.  RCCL inside the library (dst_comm_create; the id travels from rank 0
+    by a torch.distributed broadcast); if that fails on this host, the same all-gather through torch.distributed's own
+    RCCL (dst_comm_create_custom).  Rehearsal (ranks sharing one GPU): gloo through host memory."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    if rehearse:
+        def staged(d_send, d_recv, nbytes, stream):
+            assert hip.hipStreamSynchronize(stream) == 0
+            mine = torch.empty(nbytes, dtype=torch.uint8)
+            assert hip.hipMemcpy(mine.data_ptr(), d_send, nbytes, 2) == 0
+            everything = torch.empty(nbytes * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(everything, mine)
+            assert hip.hipMemcpy(d_recv, everything.data_ptr(), nbytes * world, 1) == 0
+        return da.Comm.custom(eng, rank, world, staged), "gloo through host memory (rehearsal: the ranks share one GPU)"
+    want = os.environ.get("DST_BENCH_COMM", "rccl")
+    ok = torch.zeros(1, dtype=torch.int32, device=dev)
+    comm = None
+    if want == "rccl":
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(da.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = da.Comm.rccl(eng, bytes(uid.cpu().numpy().tobytes()), rank, world)
+            ok += 1
+        except Exception as exc:   # noqa: BLE001 - the other transport below
+            print(f"[rank {rank}] RCCL inside the library is not usable here ({exc}); using torch.distributed's", file=sys.stderr)
+        dist.all_reduce(ok)
+        if int(ok.item()) == world:
+            return comm, "RCCL (ncclAllGather inside libdistance_hip.so)"
+        if comm is not None:
+            comm.close()
+    bufs = {}
 
-    def cut(T):
-        b = [0]
-        for _ in range(world):
-            x = b[-1]
-            budget = (T - prep_per_record * (n - x)) / max(s_per_pair, 1e-18)
-            if budget < 0:
-                return None
-            target = da.square_row_start(n, x) + int(budget)
-            lo, hi = x, n                       # largest row r with row_start(r) <= target
-            while hi - lo > 1:
-                mid = (lo + hi) // 2
-                if da.square_row_start(n, mid) <= target:
-                    lo = mid
-                else:
-                    hi = mid
-            b.append(lo if target < total else n)
-        return b if b[-1] >= n - 1 else None
-
-    lo_t, hi_t = 0.0, prep_per_record * n + s_per_pair * total + 1e-9
-    for _ in range(60):
-        mid = 0.5 * (lo_t + hi_t)
-        if cut(mid) is None:
-            lo_t = mid
-        else:
-            hi_t = mid
-    b = cut(hi_t)
-    b[-1] = n
-    for k in range(1, world):                   # monotone, inside [0, n]
-        b[k] = min(max(b[k], b[k - 1]), n)
-    return b
+    def through_torch(d_send, d_recv, nbytes, stream):
+        # the library's stream IS torch's current stream here: copies and the collective are ordered on it
+        if bufs.get("n") != nbytes:
+            bufs["n"] = nbytes
+            bufs["send"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            bufs["recv"] = torch.empty(nbytes * world, dtype=torch.uint8, device=dev)
+        assert stream == work_stream.cuda_stream
+        assert hip.hipMemcpyAsync(bufs["send"].data_ptr(), d_send, nbytes, 3, stream) == 0
+        dist.all_gather_into_tensor(bufs["recv"], bufs["send"])
+        assert hip.hipMemcpyAsync(d_recv, bufs["recv"].data_ptr(), nbytes * world, 3, stream) == 0
+    return da.Comm.custom(eng, rank, world, through_torch), "RCCL (torch.distributed all_gather_into_tensor)"
 
 
 def verify_rows(eng, codes, full_out, n, L, measure, rows, dev_index, stream, first_row: int = 0) -> dict:

@@ -41,6 +41,7 @@ _SIGS = {
     "dst_measure_from_name": (C.c_int, [C.c_char_p]),
     "dst_tally_width": (C.c_int, [C.c_int]),
     "dst_status_string": (C.c_char_p, [C.c_int]),
+    "dst_build_flags": (C.c_char_p, []),
     "dst_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "dst_destroy": (C.c_int, [_vp]),
     "dst_last_error": (C.c_char_p, [_vp]),
@@ -81,6 +82,7 @@ _SIGS = {
     "dst_comm_destroy": (C.c_int, [_vp]),
     "dst_upload_shared": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _vp]),
     "dst_shared_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
+    "dst_shared_block_layout": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, _u32p]),
     "dst_shared_stats": (C.c_int, [_vp, C.c_int, _u64p, _u64p, _u64p]),
     "dst_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dst_gather_slabs": (C.c_int, [_vp, _vp, _vp, _u64p, _u64p, C.c_int, _vp]),

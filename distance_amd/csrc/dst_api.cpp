@@ -296,8 +296,10 @@ int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64
     s.nblocks = (uint32_t)count;
     s.last_use = ++ctx->schedule_clock;
     if (ctx->schedules.size() >= kMaxSchedules) {
-        // evict the least recently used; an in-flight kernel may still read it
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        // evict the least recently used; a kernel queued on ANY stream may still read it (sub-slab launches alternate
+        // between streams, the caller may bring its own): wait for the device — evictions are rare, launches are not
+        (void)stream;
+        HIP_TRY(ctx, hipDeviceSynchronize());
         size_t victim = 0;
         for (size_t k = 1; k < ctx->schedules.size(); ++k)
             if (ctx->schedules[k].last_use < ctx->schedules[victim].last_use)
@@ -1058,6 +1060,12 @@ int dst_destroy(dst_ctx *ctx)
 }
 
 int dst_variant_count(int measure) { return variant_count(measure); }
+
+const char *dst_build_flags(void)
+{
+    const char *f = consensus_build_flags();
+    return *f == ' ' ? f + 1 : f;
+}
 
 int dst_set_ksplit(dst_ctx *ctx, int ksplit)
 {

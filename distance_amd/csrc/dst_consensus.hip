@@ -1171,10 +1171,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
         // Only tiles on the diagonal have to test t > q.
         const bool diag = square && panel0 <= tile.i1;
         auto apply = [&](uint32_t col, uint32_t nib, uint32_t meta) {
-#ifdef DST_DBG_NO_APPLY
-            if (col != 0xFFFFFFFFu)
-                return;
-#endif
             const uint32_t rb = meta >> 8;
             if (diag && panel0 + col <= q0 + rb)
                 return;
@@ -1295,10 +1291,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 }
                 if constexpr (OUT == OUT_INT) {
                     int64_t *out = static_cast<int64_t *>(out_v);
-#ifdef DST_DBG_NO_STORE
-                    if (o[0][0] != 0xFFFFFFF0u)
-                        return;
-#endif
                     if (live[0] && live[1]) {
                         store_result2(out + at, (int64_t)o[0][0], (int64_t)o[1][0]);
                     } else if (live[0]) {
@@ -1341,10 +1333,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     };
                     fin(0);   // (two copies of the formula: the two results' dependency chains interleave)
                     fin(1);
-#ifdef DST_DBG_NO_STORE
-                    if (d[0] != -12345.5)
-                        return;
-#endif
                     if (live[0] && live[1]) {
                         store_result2(out + at, d[0], d[1]);
                     } else if (live[0]) {
@@ -1390,10 +1378,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 } else {
                     const double d0 = finalize_pair<OUT>(o0, qc, tc0, LOGS ? logtab : kLogTab);
                     const double d1 = finalize_pair<OUT>(o1, qc, tc1, LOGS ? logtab : kLogTab);
-#ifdef DST_DBG_NO_STORE
-                    if (d0 != -12345.5)
-                        return;
-#endif
                     store_result2(static_cast<double *>(out_v) + at, d0, d1);
                 }
             };
@@ -1511,11 +1495,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
         const Inl inl_none{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u};
         Entry en_n2{0u, 0u, false};
         Inl in_cur = inl_none, in_nx = inl_none;
-#ifdef DST_DBG_NO_EVENTS
-        const bool do_events = false;
-#else
-        const bool do_events = true;
-#endif
+        constexpr bool do_events = true;
         if (do_events) {  // prologue: batch 0's and batch 1's table entries, batch 2's list entry
             in_cur = load_inl(load_entry(0, 0));
             in_nx = load_inl(load_entry(1, 0));
@@ -1946,6 +1926,34 @@ hipError_t launch_shared_splice(const uint32_t *gathered, const SharedLayout &la
     hipLaunchKernelGGL(shared_report_kernel, dim3(1), dim3(64), 0, stream, gathered, lay,
                        reinterpret_cast<const unsigned long long *>(set.ref.stats), report);
     return hipGetLastError();
+}
+
+// every measurement macro this translation unit was compiled with (dst_build_flags): a production build has none
+const char *consensus_build_flags()
+{
+    return ""
+#ifdef DST_DBG_ALIGN_JC69
+           " DST_DBG_ALIGN_JC69"
+#endif
+#ifdef DST_DBG_EVWAVES
+           " DST_DBG_EVWAVES"
+#endif
+#ifdef DST_DBG_HEAVY_EW
+           " DST_DBG_HEAVY_EW"
+#endif
+#ifdef DST_DBG_OLDMAP
+           " DST_DBG_OLDMAP"
+#endif
+#ifdef DST_DBG_PLAIN_SLICES
+           " DST_DBG_PLAIN_SLICES"
+#endif
+#ifdef DST_DBG_PLAIN_STORES
+           " DST_DBG_PLAIN_STORES"
+#endif
+#ifdef DST_DBG_RB
+           " DST_DBG_RB"
+#endif
+        ;
 }
 
 hipError_t launch_site_hist(const DeviceSet &set, uint32_t *hist, hipStream_t stream)

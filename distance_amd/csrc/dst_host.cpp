@@ -391,6 +391,20 @@ int dst_shared_range(uint64_t n, int rank, int world, uint64_t *begin, uint64_t 
     return DST_OK;
 }
 
+int dst_shared_block_layout(uint64_t n, int world, uint32_t entries, uint32_t layout[6])
+{
+    if (world < 1 || !layout)
+        return DST_ERR_ARG;
+    const SharedLayout lay = shared_layout(n, world, entries);
+    layout[0] = lay.rmax;
+    layout[1] = lay.cnt_at;
+    layout[2] = lay.counts_at;
+    layout[3] = lay.ent_at;
+    layout[4] = lay.ent_cap;
+    layout[5] = lay.words;
+    return DST_OK;
+}
+
 size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs)
 {
     if (out_kind == DST_OUT_TALLY)

@@ -257,6 +257,8 @@ hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const 
 // exact per-site counts of known G, C, T over the records of `set`, added into hist[len][3]
 hipError_t launch_site_hist(const DeviceSet &set, uint32_t *hist, hipStream_t stream);
 
+const char *consensus_build_flags();   // dst_consensus.hip: the DST_DBG_* measurement macros it was compiled with
+
 // ---- kernel launchers (dst_kernels.hip) -----------------------------------------------------
 // lists != NULL: the pack also counts every record's differences from the reference (cold and hot sites apart)
 struct PackLists {

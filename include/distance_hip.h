@@ -78,6 +78,9 @@ int dst_device_count(int *count);
 int dst_measure_from_name(const char *name);
 int dst_tally_width(int measure);
 const char *dst_status_string(int status);
+/* The measurement macros (DST_DBG_*: alternative store patterns, wave splits ... of tools/variants.sh) this library was
+ * compiled with, space separated; "" for a production build.  bench.py refuses to time anything else. */
+const char *dst_build_flags(void);
 
 /* ---- context -------------------------------------------------------------------------- */
 int dst_create(int device, dst_ctx **ctx);
@@ -249,6 +252,11 @@ int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes, size_t n, s
                       int with_counts, void *stream);
 /* the records rank `rank` of `world` prepares (pure host code) */
 int dst_shared_range(uint64_t n, int rank, int world, uint64_t *begin, uint64_t *end);
+/* The exchange block of one rank for blocks of `entries` list entries, in 32-bit words (pure host code; documentation
+ * and tests — dst_upload_shared sizes its blocks itself): layout = {records per rank, offset of the list lengths, of the
+ * base counts (4 per record), of the entries, entry capacity (rounded up to 4), words per block}.  Words 0..3 of a block:
+ * entries in it, 1 if they did not fit, the first invalid byte's index (64 bits, ~0: none). */
+int dst_shared_block_layout(uint64_t n, int world, uint32_t entries, uint32_t layout[6]);
 /* how dst_upload_shared went on this context so far: uploads that were shared, uploads that fell back to the replicated
  * form, entries of the largest exchange block of the last one (any pointer may be NULL) */
 int dst_shared_stats(const dst_ctx *ctx, int slot, uint64_t *shared_uploads, uint64_t *fallbacks, uint64_t *block_entries);

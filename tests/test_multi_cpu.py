@@ -134,33 +134,73 @@ def test_root_share_balances_the_root_finalisation():
     assert [x[0] for x in rows] == bounds[:-1] and [x[-1] for x in rows] == bounds[1:]
 
 
-def test_balanced_bounds_equalise_the_ranks():
-    """bench.py's sharded N>1 partition: preparation x records held + pair time x pairs equal over the ranks (the rank
-    that starts at row r0 holds records r0..n), monotone bounds from 0 to n, degenerate inputs included."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    start, end = src.index("def balanced_bounds"), src.index("def verify_rows")
+def _shared_worker(rank, world, port, n, L, out_path):
+    """The exchange of dst_upload_shared with numpy standing in for the device passes: every rank lists ITS records
+    (dst_shared_range), fills a block of the documented layout (dst_shared_block_layout), gloo all-gathers the blocks,
+    and the splice rules of include/distance_hip.h rebuild the CSR of the whole set."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
 
-    class DA:
-        @staticmethod
-        def square_row_start(n, i):
-            return i * (2 * n - i - 1) // 2
+    import distance_amd as da
+    import oracle
+    from helpers import random_alignment
 
-    ns = {"da": DA}
-    exec("from __future__ import annotations\n" + src[start:end], ns)
-    balanced_bounds = ns["balanced_bounds"]
-    assert spec is not None
-    n, prep, pair = 50_000, 0.9e-3 / 50_000, 2.1e-3 / 1.25e9
-    for world in (2, 3, 4, 8):
-        b = balanced_bounds(n, world, prep, pair)
-        assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:])) and len(b) == world + 1
-        t = [prep * (n - b[k]) + pair * (DA.square_row_start(n, b[k + 1]) - DA.square_row_start(n, b[k])) for k in range(world)]
-        assert max(t) - min(t) < 0.02 * max(t), (world, b, t)
-    # no preparation cost: equal pair counts; tiny sets: still a partition of [0, n]
-    b = balanced_bounds(1000, 4, 0.0, 1e-9)
-    pairs = [DA.square_row_start(1000, b[k + 1]) - DA.square_row_start(1000, b[k]) for k in range(4)]
-    assert max(pairs) - min(pairs) <= 2 * 1000
-    for nn, w in ((2, 2), (3, 8), (10, 3)):
-        b = balanced_bounds(nn, w, 1e-6, 1e-6)
-        assert b[0] == 0 and b[-1] == nn and all(x <= y for x, y in zip(b, b[1:])) and len(b) == w + 1
+    codes = random_alignment(n, L, seed=321, divergence=0.01)
+    ref = oracle.consensus(codes)
+    begin, end = da.shared_range(n, rank, world)
+    lists = [oracle.get_differences(codes[r], ref) for r in range(begin, end)]
+    lay = (C.c_uint32 * 6)()
+    assert da.load().dst_shared_block_layout(n, world, 40 * max(end - begin, 1) + 64, lay) == 0
+    rmax, cnt_at, _counts_at, ent_at, cap, words = (int(x) for x in lay)
+    block = np.zeros(words, np.uint32)
+    total = sum(len(x) for x in lists)
+    block[0], block[1] = total, int(total > cap)
+    block[2], block[3] = 0xFFFFFFFF, 0xFFFFFFFF
+    block[cnt_at:cnt_at + len(lists)] = [len(x) for x in lists]
+    if lists and total <= cap:
+        block[ent_at:ent_at + total] = np.concatenate(lists + [np.zeros(0, np.uint64)]).astype(np.uint32)
+    # the block size must be the same everywhere: the capacity is derived from rank-independent figures in the product;
+    # here every rank used its own count, so agree on the largest first
+    size = torch.tensor([words], dtype=torch.int64)
+    dist.all_reduce(size, op=dist.ReduceOp.MAX)
+    padded = np.zeros(int(size.item()), np.uint32)
+    padded[:words] = block
+    everything = torch.empty(int(size.item()) * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(everything, torch.from_numpy(padded.view(np.int32)))
+    blocks = everything.numpy().view(np.uint32).reshape(world, -1)
+    # splice: record r belongs to rank r // rmax, its length is that block's cnt[r % rmax]; a rank's entries go to the
+    # offset of its first record
+    lengths = np.array([blocks[r // rmax][cnt_at + r % rmax] for r in range(n)], np.int64)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    ent = np.zeros(off[-1], np.uint32)
+    for k in range(world):
+        b = min(k * rmax, n)
+        ent[off[b]:off[b] + blocks[k][0]] = blocks[k][ent_at:ent_at + blocks[k][0]]
+    if rank == world - 1:
+        np.savez(out_path, off=off, ent=ent)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 700), (3, 1000), (3, 300)])
+def test_shared_preparation_blocks_splice_into_the_whole_sets_lists(tmp_path, world, n):
+    import distance_amd as da
+    import oracle
+    from helpers import random_alignment
+    L = 400
+    out = str(tmp_path / "csr.npz")
+    mp.spawn(_shared_worker, args=(world, _free_port(), n, L, out), nprocs=world, join=True)
+    got = np.load(out)
+    codes = random_alignment(n, L, seed=321, divergence=0.01)
+    ref = oracle.consensus(codes)
+    for r in range(n):
+        want = oracle.get_differences(codes[r], ref)
+        assert np.array_equal(got["ent"][got["off"][r]:got["off"][r + 1]], want.astype(np.uint32)), r
+    # the ranks' shares tile [0, n) in order, whole waves of 256 records each
+    edges = [da.shared_range(n, k, world) for k in range(world)]
+    assert edges[0][0] == 0 and edges[-1][1] == n and all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+    assert all((e - b) % 256 == 0 or e == n for b, e in edges)

@@ -8,5 +8,5 @@ done
 timeout -k 10 300 python bench.py --workload C4 > $O/bench_C4.json 2> $O/bench_C4.err || echo "bench C4 failed"
 timeout -k 10 400 python tools/cbench.py --reps 3 > $O/cbench_paths_c3.txt 2>&1
 timeout -k 10 300 python tools/nsweep.py > $O/nsweep_paths.txt 2>&1
-timeout -k 5 120 tools/ubench/store_rate 50000 32 1 > $O/ubench_store_rate.txt 2>&1
+make -s -C tools/ubench store_rate && timeout -k 5 120 tools/ubench/store_rate 50000 32 1 > $O/ubench_store_rate.txt 2>&1
 echo refresh done

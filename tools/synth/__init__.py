@@ -65,3 +65,46 @@ def fasta_bytes(seed: int, codes: np.ndarray, first: int = 0, prefix: str = "s")
         _lib().synth_letters(seed, row.ctypes.data, L, first + k, buf)
         parts.append(b">" + f"{prefix}{first + k}".encode() + b"\n" + buf.raw[:L] + b"\n")
     return b"".join(parts)
+
+
+# ---- committed variants of the §8(d) alignment: the data-dependence of the consensus path (bench.py legs, tests) ----
+_NEXT_BASE = {136: 72, 72: 40, 40: 24, 24: 136}   # A -> G -> C -> T -> A
+
+
+def clade_plan(seed: int, n: int, L: int, share: float = 0.33, site_share: float = 0.02):
+    """Clade structure: `share` of the records carry the same substitution at `site_share` of the sites (clade-defining
+    mutations: columns where a third of the alignment deviates from the plurality).  Returns (records, sites), sorted."""
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, n, L, 0xC1ADE])
+    return np.nonzero(rng.random(n) < share)[0], np.nonzero(rng.random(L) < site_share)[0]
+
+
+def nrun_plan(seed: int, n: int, L: int, share: float = 0.05, frac: float = 0.5):
+    """Records with long runs of N (failed amplicons, partial genomes): `share` of the records get 1-3 runs of N covering
+    `frac` of their sites.  Returns a list of (record, first site, width)."""
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, n, L, 0x2B5])
+    plan = []
+    for r in np.nonzero(rng.random(n) < share)[0]:
+        runs = int(rng.integers(1, 4))
+        w = int(frac * L / runs)
+        for _ in range(runs):
+            plan.append((int(r), int(rng.integers(0, L - w + 1)), w))
+    return plan
+
+
+def apply_clades(codes, root_codes: np.ndarray, records: np.ndarray, sites: np.ndarray):
+    """In place on a numpy array or a torch tensor (any device) of Paradis codes."""
+    nxt = np.array([_NEXT_BASE.get(int(c), int(c)) for c in root_codes[sites]], np.uint8)
+    if isinstance(codes, np.ndarray):
+        codes[np.ix_(records, sites)] = nxt[None, :]
+        return codes
+    import torch
+    r = torch.from_numpy(records).to(codes.device)
+    s = torch.from_numpy(sites).to(codes.device)
+    codes[r[:, None], s[None, :]] = torch.from_numpy(nxt).to(codes.device)[None, :].expand(len(r), -1)
+    return codes
+
+
+def apply_nruns(codes, plan):
+    for r, a, w in plan:
+        codes[r, a:a + w] = 0xF0
+    return codes

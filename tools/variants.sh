@@ -3,9 +3,7 @@
 # -> build/variants/libdistance_hip_<name>.so (select with DST_LIB_PATH; tools/variants_run.sh / variants_prof.sh /
 # variants_calib.sh run cbench / rocprofv3 / calibrate on each).  Only dst_consensus.hip is rebuilt.
 # Knobs (all compiled out of the product build; what each one answered is in DESIGN.md 3b):
-#   -DDST_DBG_NO_EVENTS     event waves idle: the output phase alone (the store floor)
-#   -DDST_DBG_NO_STORE      results computed, not stored: the event side + skeleton alone
-#   -DDST_DBG_NO_APPLY      event loads issued, LDS atomics skipped
+#   (the work-skipping knobs of r02 — NO_EVENTS / NO_STORE / NO_APPLY — are gone from the kernel: r03)
 #   -DDST_DBG_PLAIN_STORES  default-policy stores instead of nontemporal ones
 #   -DDST_DBG_OLDMAP        panel-relative column mapping for every family (no address-aligned quarters)
 #   -DDST_DBG_EVWAVES=k     k event waves + 8-k output waves for every launch
@@ -19,7 +17,7 @@ while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c $SRC.hip -o ../../build/variants/${SRC}_$name.o
   objs=""
-  for o in dst_kernels dst_consensus dst_text dst_api dst_stream dst_host dst_gather; do
+  for o in dst_kernels dst_consensus dst_text dst_api dst_stream dst_host dst_gather dst_shared; do
     if [ $o = $SRC ]; then objs="$objs ../../build/variants/${SRC}_$name.o"; else objs="$objs ../../build/obj/$o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -no-hip-rt $objs \
