@@ -89,7 +89,12 @@ OPS_PER_WORD = {"n": 5, "n_high": 5, "raw": 7, "jc69": 7, "k80": 7, "tn93": 8}  
 RAW_STEP_CEILING_NS = 10.6
 # consensus path: f64 VALU instructions of the fused finalisation per pair (ISA of consensus_pair_kernel: conversions,
 # the expanded division sequences, dst_log's polynomial), and the f64 vector peak in fma lanes per second
-F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 8, "jc69": 34, "k80": 56, "tn93": 234}   # counted in build/asm/dst_consensus.s
+F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 8, "jc69": 18, "k80": 33, "tn93": 117}   # tools/count_f64_ops.py (refreshed below)
+try:   # the committed count of the current epilogue (python tools/count_f64_ops.py > profiles/r03/f64_ops.json)
+    with open(os.path.join(ROOT, "profiles", "r03", "f64_ops.json")) as _fh:
+        F64_OPS_PER_PAIR.update({m: rec["epilogue"]["f64"] for m, rec in json.load(_fh).items()})
+except Exception:
+    pass
 F64_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
 
 
@@ -287,8 +292,24 @@ def main():
                                      "over the wall time of a step (pack, lists, tables, pair kernel, launch gaps and the upload's wait)"}
         return leg
 
-    def bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
-        return bool(torch.equal(a.view(torch.int64), b.view(torch.int64)))
+    def bits_equal_dense(out: torch.Tensor, m: str, data: torch.Tensor) -> bool:
+        """every result in `out` (the whole triangle) against the dense bit-plane kernels on the same input, bit for bit:
+        untimed dense runs over row slabs of at most 2^30 pairs (200,000 x 1,000 has 160 GB of results: no second copy)"""
+        eng.set_path("dense")
+        eng.upload_device(0, data.data_ptr(), n, L, data.stride(0), None, stream)
+        slab = torch.empty(min(max(total_pairs, 1), 1 << 30), dtype=out.dtype, device=dev)
+        ok, r0 = True, 0
+        while r0 < n - 1 and ok:
+            r1 = r0 + 1
+            while r1 < n - 1 and da.square_row_start(n, r1 + 1) - da.square_row_start(n, r0) <= slab.numel():
+                r1 += 1
+            lo, hi = da.square_row_start(n, r0), da.square_row_start(n, r1)
+            eng.run_square_device(m, r0, r1, slab.data_ptr(), slab.numel() * 8, stream=stream)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(slab[:hi - lo].view(torch.int64), out[lo:hi].view(torch.int64)))
+            r0 = r1
+        del slab
+        return ok
 
     def oracle_rows(out: torch.Tensor, m: str, data_host: np.ndarray, rows) -> dict:
         """rows of the job's result against the oracle (restated reference algorithm, libm): integers and raw bit-exact
@@ -347,7 +368,7 @@ def main():
             f64_rate = launch_pairs * f64_ops / (k_ms * 1e-3)
             valu = {"bound": "valu", "achieved": f64_rate / 1e12, "peak": F64_PEAK_LANE_OPS / 1e12, "unit": "T f64-lane-op/s",
                     "frac": f64_rate / F64_PEAK_LANE_OPS, "kernel": kernel, "kernel_ms": k_ms, "f64_ops_per_pair": f64_ops,
-                    "note": "f64 finalisation instructions per pair (divisions expanded, table-driven log) x pairs against the "
+                    "note": "f64 instructions of one finalisation in the kernel's ISA (tools/count_f64_ops.py) x pairs against the "
                             "f64 vector peak (78.6 TFLOP/s = 39.3e12 fma lanes/s); measured issue cost of one f64 op: "
                             "profiles/r02/ubench_f64_rate.txt"}
             if valu["frac"] > hbm["frac"]:
@@ -364,30 +385,24 @@ def main():
 
     if world == 1:
         full_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)
-        check_out = torch.empty(max(total_pairs, 1), dtype=out_dtype, device=dev)   # the dense path's results, for verify
         legs = {}
         verify = {"against": "the dense bit-plane path on the same inputs, every result bit for bit (torch.equal on the int64 "
                              "views), and sampled rows against the oracle (restated reference algorithm with libm)"}
         sample_rows = sorted({r for r in (0, n // 2, n - 2) if 0 <= r < n - 1})
         main_leg = single_gpu_leg(measure, args.path, full_out)
         if main_leg["path_used"] != "dense":
-            if not args.no_extra:
-                legs["dense"] = single_gpu_leg(measure, "dense", check_out)
-            else:   # still verify: one untimed dense run
-                eng.set_path("dense")
-                eng.upload_device(0, codes.data_ptr(), n, L, codes.stride(0), None, stream)
-                eng.run_square_device(measure, 0, n, check_out.data_ptr(), check_out.numel() * 8, stream=stream)
-                torch.cuda.synchronize()
-            verify["default_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+            verify["default_vs_dense_bits_equal"] = bits_equal_dense(full_out, measure, codes)
         verify["oracle_" + measure] = oracle_rows(full_out, measure, host_codes_full, sample_rows)
+        if not args.no_extra and main_leg["path_used"] != "dense":
+            legs["dense"] = single_gpu_leg(measure, "dense", full_out)
         if not args.no_extra:
             if stock and args.workload == "C3raw":
                 legs["tn93"] = single_gpu_leg("tn93", args.path, full_out)
                 verify["oracle_tn93"] = oracle_rows(full_out, "tn93", host_codes_full, sample_rows[:2])
                 if legs["tn93"]["path_used"] != "dense":
-                    legs["tn93_dense"] = single_gpu_leg("tn93", "dense", check_out)
                     # device-finalised f64 of two kernels: the same tallies through the same finalisation code
-                    verify["tn93_default_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+                    verify["tn93_default_vs_dense_bits_equal"] = bits_equal_dense(full_out, "tn93", codes)
+                    legs["tn93_dense"] = single_gpu_leg("tn93", "dense", full_out)
                 # ---- the same shape, other data: the consensus path's time depends on the alignment
                 root_codes = synth.root(args.seed ^ config_id, L)
                 variants = {
@@ -403,12 +418,7 @@ def main():
                     torch.cuda.synchronize()
                     leg = single_gpu_leg(measure, args.path, full_out, data=var, steps=max(3, args.steps // 2))
                     leg["data"] = what
-                    eng.set_path("dense")
-                    eng.upload_device(0, var.data_ptr(), n, L, var.stride(0), None, stream)
-                    eng.run_square_device(measure, 0, n, check_out.data_ptr(), check_out.numel() * 8, stream=stream)
-                    torch.cuda.synchronize()
-                    leg["dense_ms"] = eng.last_kernel_ms()["pair_ms"]
-                    verify[name + "_vs_dense_bits_equal"] = bits_equal(full_out, check_out)
+                    verify[name + "_vs_dense_bits_equal"] = bits_equal_dense(full_out, measure, var)
                     legs[name] = leg
                     del var
             eng.set_path(args.path)

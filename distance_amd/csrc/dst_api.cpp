@@ -1351,6 +1351,8 @@ int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int
         return DST_ERR_ARG;
     if (measure < DST_N || measure > DST_TN93)
         return fail(ctx, DST_ERR_ARG, "unknown measure");
+    const bool close = (tally_kind & DST_FIN_CLOSE) != 0;
+    tally_kind &= ~DST_FIN_CLOSE;
     if (tally_kind != DST_OUT_TALLY && tally_kind != DST_OUT_TALLY16)
         return fail(ctx, DST_ERR_ARG, "tally_kind must be DST_OUT_TALLY or DST_OUT_TALLY16");
     if (row_slot < 0 || row_slot > 1 || col_slot < 0 || col_slot > 1)
@@ -1384,7 +1386,7 @@ int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int
     pl.row_begin = row_begin;
     pl.row_end = row_end;
     pl.out_base = square ? square_row_start(cols.n, row_begin) : 0;
-    HIP_TRY(ctx, launch_finalize(measure, pl, d_tallies, tally_kind == DST_OUT_TALLY16, d_out, stream));
+    HIP_TRY(ctx, launch_finalize(measure, pl, d_tallies, tally_kind == DST_OUT_TALLY16, d_out, stream, close));
     if (!stream_v)
         HIP_TRY(ctx, hipStreamSynchronize(stream));
     return DST_OK;

@@ -184,6 +184,100 @@ __device__ __forceinline__ double fin_tn93(uint32_t count_L, uint32_t count_d, u
     return d;
 }
 
+// ---- the fused epilogue's own arithmetic (DST_OUT_DISTANCE, dst_finalize_device): within 1e-12, not in the reference's order ----
+// The pair kernels of jc69 / k80 / tn93 spend their time in this code (tn93: 234 f64 instructions per pair in the
+// reference's operation order — five IEEE divisions, fourteen corrected quotients, three table logarithms), and nothing
+// needs its last bits any more: the TSV text is finalised from the tallies by number_kernel with the functions above
+// and the host's libm for the near ties (dst_text.hip), DST_OUT_TALLY + dst_finalize give the reference's bits.  So for
+// the low-diversity alignments the consensus path exists for — every logarithm's argument within 2^-5 of 1 — the
+// distance is evaluated as sums of -ln(1 - e) = e + e^2/2 + ... + e^9/9 (remainder below 3e-15 of the value) with
+// reciprocals from the f32 unit and one Newton step (2^-44) and no quotient corrections: ~105 instructions for tn93,
+// ~20 for jc69, ~32 for k80, absolute error below 1e-13.  Anything else — an argument further from 1, zero
+// denominators, tallies of 2^24 and more, NaN — takes the functions above.
+__device__ __forceinline__ double rcp_fast(double b)   // b > 0, inside the f32 range
+{
+    const double y0 = (double)__builtin_amdgcn_rcpf((float)b);
+    return fma(y0, fma(-b, y0, 1.0), y0);
+}
+
+// -ln(1 - e) for 0 <= e < 2^-5
+__device__ __forceinline__ double neg_ln1m(double e)
+{
+    double q = 1.0 / 9.0;
+    q = fma(q, e, 1.0 / 8.0);
+    q = fma(q, e, 1.0 / 7.0);
+    q = fma(q, e, 1.0 / 6.0);
+    q = fma(q, e, 1.0 / 5.0);
+    q = fma(q, e, 1.0 / 4.0);
+    q = fma(q, e, 1.0 / 3.0);
+    q = fma(q, e, 1.0 / 2.0);
+    q = fma(q, e, 1.0);
+    return q * e;
+}
+constexpr double kSeriesMax = 0x1p-5;
+
+__device__ __attribute__((noinline)) double fin_jc69_close(uint32_t n, uint32_t d, const LogEntry *tab) { return fin_jc69(n, d, tab); }
+__device__ __attribute__((noinline)) double fin_k80_close(uint32_t count_L, uint32_t ts, uint32_t tv, const LogEntry *tab)
+{
+    return fin_k80(count_L, ts, tv, tab);
+}
+__device__ __attribute__((noinline)) double fin_tn93_close(uint32_t count_L, uint32_t count_d, uint32_t count_P1, uint32_t count_P2,
+                                                           uint4 qc, uint4 tc, const LogEntry *tab)
+{
+    return fin_tn93(count_L, count_d, count_P1, count_P2, qc, tc, tab);
+}
+
+__device__ __forceinline__ double fin_jc69_fast(uint32_t n, uint32_t d, const LogEntry *tab)
+{
+    if (n == 0 && d != 0)
+        return -0.0;   // -0.75 * ln(1): the reference's sign (src/measures.rs:76)
+    const double e = (4.0 / 3.0) * ((double)n * rcp_fast((double)d));
+    if (d == 0 || !(e < kSeriesMax))
+        return fin_jc69_close(n, d, tab);
+    return 0.75 * neg_ln1m(e);
+}
+
+__device__ __forceinline__ double fin_k80_fast(uint32_t count_L, uint32_t ts, uint32_t tv, const LogEntry *tab)
+{
+    if ((ts | tv) == 0 && count_L != 0)
+        return -0.0;   // -0.5 * ln(1 * sqrt(1))
+    const double inv_L = rcp_fast((double)count_L);
+    const double P = (double)ts * inv_L, Q = (double)tv * inv_L;
+    const double ea = 2.0 * P + Q, eb = 2.0 * Q;   // -0.5 ln((1 - ea) sqrt(1 - eb)) = 0.5 S(ea) + 0.25 S(eb)
+    if (count_L == 0 || !(ea < kSeriesMax))         // (eb <= ea)
+        return fin_k80_close(count_L, ts, tv, tab);
+    return 0.5 * neg_ln1m(ea) + 0.25 * neg_ln1m(eb);
+}
+
+__device__ __forceinline__ double fin_tn93_fast(uint32_t count_L, uint32_t count_d, uint32_t count_P1, uint32_t count_P2, uint4 qc,
+                                                uint4 tc, const LogEntry *tab)
+{
+    const uint64_t sA = (uint64_t)tc.x + qc.x, sT = (uint64_t)tc.y + qc.y, sG = (uint64_t)tc.z + qc.z, sC = (uint64_t)tc.w + qc.w;
+    // every product below needs its factors non-zero; counts of 2^24 and more (alignments beyond 16 M sites) go the long way
+    const bool plain = sA != 0 && sG != 0 && sT != 0 && sC != 0 && count_L != 0 && ((sA | sT | sG | sC | (uint64_t)count_L) >> 24) == 0;
+    if (!plain)
+        return fin_tn93_close(count_L, count_d, count_P1, count_P2, qc, tc, tab);
+    const double A = (double)sA, G = (double)sG, T = (double)sT, C = (double)sC;
+    const double R = (double)(sA + sG), Y = (double)(sT + sC), L = (double)(sA + sG + sT + sC);
+    const double AG = A * G, TC = T * C;
+    const double iR = rcp_fast(R), iY = rcp_fast(Y), iL = rcp_fast(L), icL = rcp_fast((double)count_L);
+    const double iAG = rcp_fast(AG), iTC = rcp_fast(TC);
+    // P1 / k1 = P1 L R / (2 A G);  Q / (2 g_R) = Q L / (2 R);  Q / (2 g_R g_Y) = Q L^2 / (2 R Y)      (g_X = X / L)
+    const double u = icL * L;
+    const double hq = 0.5 * (double)(count_d - (count_P1 + count_P2)) * u;
+    const double e1 = fma(hq, iR, 0.5 * ((double)count_P1 * u) * (R * iAG));
+    const double e2 = fma(hq, iY, 0.5 * ((double)count_P2 * u) * (Y * iTC));
+    const double e3 = (hq * L) * (iR * iY);
+    if (!(e1 < kSeriesMax && e2 < kSeriesMax && e3 < kSeriesMax))
+        return fin_tn93_close(count_L, count_d, count_P1, count_P2, qc, tc, tab);
+    const double k1 = 2.0 * AG * (iL * iR), k2 = 2.0 * TC * (iL * iY);
+    const double k3 = 2.0 * (iL * iL) * (R * Y - AG * (Y * iR) - TC * (R * iY));
+    double d = k1 * neg_ln1m(e1) + k2 * neg_ln1m(e2) + k3 * neg_ln1m(e3);
+    if (d == 0.0)
+        d = 0.0;
+    return d;
+}
+
 constexpr int OUT_TALLY = -1;      // uint32 x NT site tallies per pair
 constexpr int OUT_INT = -2;        // int64 (n / n_high)
 constexpr int OUT_TALLY_ADD = -3;  // split-L launch: atomicAdd partial tallies into a zeroed buffer
@@ -191,17 +285,27 @@ constexpr int OUT_INT_ADD = -4;    // split-L launch: atomicAdd partial counts i
 constexpr int OUT_TALLY16 = -5;    // uint16 x NT per pair (alignments shorter than 65,536 sites)
 // OUT >= 0: the measure id whose f64 distance the epilogue writes
 
-template <int MEASURE>
+// CLOSE: the reference's operation order with the table logarithm — within a few ulp of the host's libm (the text path,
+// dst_finalize_device with DST_FIN_CLOSE); else the epilogue's arithmetic above (within 1e-12).  raw is the same either way.
+template <int MEASURE, bool CLOSE = false>
 __device__ __forceinline__ double finalize_pair(const uint32_t *o, uint4 qc, uint4 tc, const LogEntry *tab = kLogTab)
 {
     if constexpr (MEASURE == DST_RAW)
         return fin_raw(o[0], o[1]);
     else if constexpr (MEASURE == DST_JC69)
-        return fin_jc69(o[0], o[1], tab);
+        return CLOSE ? fin_jc69(o[0], o[1], tab) : fin_jc69_fast(o[0], o[1], tab);
     else if constexpr (MEASURE == DST_K80)
-        return fin_k80(o[0], o[1], o[2], tab);
+        return CLOSE ? fin_k80(o[0], o[1], o[2], tab) : fin_k80_fast(o[0], o[1], o[2], tab);
     else
-        return fin_tn93(o[0], o[1], o[2], o[3], qc, tc, tab);
+        return CLOSE ? fin_tn93(o[0], o[1], o[2], o[3], qc, tc, tab) : fin_tn93_fast(o[0], o[1], o[2], o[3], qc, tc, tab);
+}
+
+// the same out of line: for kernels whose registers belong to their main loop (the dense pair kernels' sweep over L)
+template <int MEASURE>
+__device__ __attribute__((noinline)) double finalize_pair_call(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint4 qc, uint4 tc)
+{
+    const uint32_t o[4] = {o0, o1, o2, o3};
+    return finalize_pair<MEASURE>(o, qc, tc);
 }
 
 }  // namespace

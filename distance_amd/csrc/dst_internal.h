@@ -277,8 +277,9 @@ hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream);
 hipError_t launch_derive(const DeviceSet &set, hipStream_t stream);   // planes K, X1, X0, CL of a lean set from its base planes
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
+// close: the reference's operation order with the table logarithm (what the text path uses), not the epilogue's arithmetic
 hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,
-                           void *d_out, hipStream_t stream);
+                           void *d_out, hipStream_t stream, bool close = false);
 TileShape tile_shape(int measure, int variant);
 int variant_count(int measure);
 

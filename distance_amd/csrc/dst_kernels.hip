@@ -604,7 +604,10 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
                     }
                     const uint64_t at = square ? (tri_row_start(n_cols, i) - out_base) + (j - i - 1)
                                                : (uint64_t)(i - row_begin) * n_cols + j;
-                    out[at] = finalize_pair<OUT>(o, qc, tc);
+                    if constexpr (OUT == DST_RAW)
+                        out[at] = finalize_pair<OUT>(o, qc, tc);
+                    else   // out of line: the epilogue must not cost the sweep over L its registers
+                        out[at] = finalize_pair_call<OUT>(o[0], o[1], NT > 2 ? o[2] : 0u, NT > 3 ? o[3] : 0u, qc, tc);
                 }
             }
         }
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256, MINW) void pair_kernel(
 // after split-L launches (whose partial tallies meet in a scratch buffer) and by
 // dst_finalize_device (tallies gathered from other GPUs).  One block per row of the range;
 // threads stride along the row's pairs (coalesced).  T = uint32_t or uint16_t tallies.
-template <int MEASURE, class T>
+template <int MEASURE, class T, bool CLOSE>
 __global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tallies,
                                                        const uint32_t *__restrict__ q_counts,
                                                        const uint32_t *__restrict__ t_counts,
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const T *__restrict__ tal
         } else {
             if constexpr (MEASURE == DST_TN93)
                 tc = reinterpret_cast<const uint4 *>(t_counts)[jstart + k];
-            static_cast<double *>(out_v)[at] = finalize_pair<MEASURE>(o, qc, tc);
+            static_cast<double *>(out_v)[at] = finalize_pair<MEASURE, CLOSE>(o, qc, tc);
         }
     }
 }
@@ -821,23 +824,25 @@ hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStrea
 #undef DST_CASE
 
 hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tallies, bool tallies16,
-                           void *d_out, hipStream_t stream)
+                           void *d_out, hipStream_t stream, bool close)
 {
     const unsigned rows = (unsigned)(pl.row_end - pl.row_begin);
     if (rows == 0)
         return hipSuccess;
-#define DST_FIN(MEAS)                                                                               \
-    do {                                                                                            \
-        if (tallies16)                                                                              \
-            hipLaunchKernelGGL((finalize_kernel<MEAS, uint16_t>), dim3(rows), dim3(256), 0, stream, \
-                               static_cast<const uint16_t *>(d_tallies), pl.rows->counts,           \
-                               pl.cols->counts, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, \
-                               pl.out_base, pl.square ? 1 : 0);                                     \
-        else                                                                                        \
-            hipLaunchKernelGGL((finalize_kernel<MEAS, uint32_t>), dim3(rows), dim3(256), 0, stream, \
-                               static_cast<const uint32_t *>(d_tallies), pl.rows->counts,           \
-                               pl.cols->counts, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, \
-                               pl.out_base, pl.square ? 1 : 0);                                     \
+#define DST_FIN2(MEAS, T, CL)                                                                                        \
+    hipLaunchKernelGGL((finalize_kernel<MEAS, T, CL>), dim3(rows), dim3(256), 0, stream, static_cast<const T *>(d_tallies), \
+                       pl.rows->counts, pl.cols->counts, d_out, (uint32_t)pl.cols->n, (uint32_t)pl.row_begin, pl.out_base, \
+                       pl.square ? 1 : 0)
+#define DST_FIN(MEAS)                             \
+    do {                                          \
+        if (tallies16 && close)                   \
+            DST_FIN2(MEAS, uint16_t, true);       \
+        else if (tallies16)                       \
+            DST_FIN2(MEAS, uint16_t, false);      \
+        else if (close)                           \
+            DST_FIN2(MEAS, uint32_t, true);       \
+        else                                      \
+            DST_FIN2(MEAS, uint32_t, false);      \
     } while (0)
     switch (measure) {
     case DST_N:
@@ -849,6 +854,7 @@ hipError_t launch_finalize(int measure, const PairLaunch &pl, const void *d_tall
     default: return hipErrorInvalidValue;
     }
 #undef DST_FIN
+#undef DST_FIN2
     return hipGetLastError();
 }
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void number_kernel(const void *__restrict__ re
             qc = reinterpret_cast<const uint4 *>(row_counts)[row];
             tc = reinterpret_cast<const uint4 *>(col_counts)[col];
         }
-        ok = put_fixed12(finalize_pair<SRC>(o, qc, tc), t.c, len, near);
+        ok = put_fixed12(finalize_pair<SRC, true>(o, qc, tc), t.c, len, near);
     }
     if (!ok) {
         atomicOr(&flags[0], 1u);

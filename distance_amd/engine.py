@@ -17,6 +17,7 @@ MEASURES = {"n": 0, "n_high": 1, "raw": 2, "jc69": 3, "k80": 4, "tn93": 5}
 INT_MEASURES = ("n", "n_high")
 FLOAT_MEASURES = ("raw", "jc69", "k80", "tn93")
 OUT_DISTANCE, OUT_TALLY, OUT_TALLY16 = 0, 1, 2
+FIN_CLOSE = 0x100
 PATHS = {"auto": 0, "dense": 1, "consensus": 2, "hybrid": 3}
 
 
@@ -298,11 +299,12 @@ class Engine:
 
     def finalize_device(self, measure, row_begin: int, row_end: int, d_tallies: int, d_out: int, capacity: int,
                         tally_kind: int = OUT_TALLY16, square: bool = True, row_slot: int = 0, col_slot: int = 0,
-                        stream: int | None = None):
-        """Tallies already on this GPU (OUT_TALLY / OUT_TALLY16 layout) -> distances (dst_finalize_device)."""
+                        stream: int | None = None, close: bool = False):
+        """Tallies already on this GPU (OUT_TALLY / OUT_TALLY16 layout) -> distances (dst_finalize_device).
+        close: the text path's arithmetic (reference operation order, table logarithm) instead of the epilogue's."""
         m = _measure_id(measure)
         self._check(self._lib.dst_finalize_device(self._h, m, int(square), row_slot, col_slot, row_begin, row_end,
-                                                  tally_kind, d_tallies, d_out, capacity, stream))
+                                                  tally_kind | (FIN_CLOSE if close else 0), d_tallies, d_out, capacity, stream))
 
     def run_rect_device(self, measure, row_slot: int, col_slot: int, row_begin: int, row_end: int,
                         d_out: int, capacity: int, tallies: bool = False, stream: int | None = None):

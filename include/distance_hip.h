@@ -57,9 +57,11 @@ typedef enum {
 
 /* What a run writes per pair, in canonical order:
  *  DST_OUT_DISTANCE: 8 bytes — the payload of FloatInt (src/measures.rs:5-9): int64 for n/n_high,
- *                    f64 for raw/jc69/k80/tn93 finalised ON DEVICE in the pair kernel's epilogue
- *                    (reference operation order, ocml log/sqrt: within 1e-12 of the reference,
- *                    not bit-identical).
+ *                    f64 for raw/jc69/k80/tn93 finalised ON DEVICE in the pair kernel's epilogue: raw is the
+ *                    reference's bits (one correctly rounded division); jc69 / k80 / tn93 are within 1e-12 of the
+ *                    reference (series logarithms and reciprocal multiplies where every logarithm's argument lies
+ *                    within 2^-5 of 1, the reference's operation order with a table logarithm elsewhere), not
+ *                    bit-identical: for the reference's bits take DST_OUT_TALLY + dst_finalize, for its TEXT dst_text_*.
  *  DST_OUT_TALLY:    dst_tally_width(measure) x uint32 site tallies, bit-exact integers:
  *                      n, n_high : {d}
  *                      raw, jc69 : {n, d}                        (src/measures.rs:57-66)
@@ -70,6 +72,9 @@ typedef enum {
  *                    than 65,536 sites: the compact form sent between GPUs; dst_finalize_device()
  *                    turns it into distances on the receiving GPU. */
 typedef enum { DST_OUT_DISTANCE = 0, DST_OUT_TALLY = 1, DST_OUT_TALLY16 = 2 } dst_output;
+/* OR-ed into dst_finalize_device's tally_kind: finalise in the reference's operation order with the device's table
+ * logarithm (within a few ulp of the host's libm: what dst_text_* prints from) instead of the epilogue's arithmetic */
+#define DST_FIN_CLOSE 0x100
 
 /* ---- library ------------------------------------------------------------------------- */
 int dst_abi_version(void);
@@ -170,7 +175,8 @@ int dst_run_rect(dst_ctx *ctx, int measure, int row_slot, int col_slot, uint64_t
                  void *stream);
 /* Tallies (DST_OUT_TALLY or DST_OUT_TALLY16 layout, canonical order of rows [row_begin,row_end))
  * that are already in this GPU's memory -> the DST_OUT_DISTANCE payload in d_out, with the same
- * device arithmetic as a direct DST_OUT_DISTANCE run (bitwise the same values).  The two sets must
+ * device arithmetic as a direct DST_OUT_DISTANCE run (bitwise the same values; tally_kind | DST_FIN_CLOSE: the text
+ * path's arithmetic instead).  The two sets must
  * be uploaded on this context (tn93 reads their base counts).  Multi-GPU: rank 0 finalises the
  * compact tallies it gathered from the other ranks. */
 int dst_finalize_device(dst_ctx *ctx, int measure, int square, int row_slot, int col_slot,

@@ -6,8 +6,12 @@ on the engine's tallies — which are bit-exact integers, checked against the or
 `oracle.tsv_square(oracle.finalize_square(tallies))` IS the reference's text for these inputs.
 
 What is counted (and written to gpurun_out/text_identity.json, copied to profiles/):
-  f64_bits_differ   device-finalised DST_OUT_DISTANCE values whose bits are not the host's (the device's log is not libm)
-  naive_lines_differ  lines that WOULD differ if the device's values were printed as they are (the r02 text path)
+  f64_bits_differ   device values in the text path's arithmetic (reference operation order, table logarithm:
+                    dst_finalize_device | DST_FIN_CLOSE) whose bits are not the host's — the device's log is not libm;
+                    max_ulp is their largest distance (the near-tie guard is 32-64 ulp wide)
+  max_abs_err       DST_OUT_DISTANCE (the pair kernels' own epilogue: series logarithms, reciprocal multiplies) against
+                    the host value: BASELINE's 1e-12
+  naive_lines_differ  lines that WOULD differ if the text path's device values were printed as they are (the r02 text path)
   lines_differ      lines of dst_text_square that differ from the reference's text — must be 0
   near_ties / rewritten   what dst_text_stats reports: values re-finalised on the host, and how many changed digits
 """
@@ -22,6 +26,7 @@ import oracle
 from helpers import KNOWN
 from tools import synth
 
+torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 LOGM = ("jc69", "k80", "tn93")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -73,12 +78,22 @@ def identity_counts(eng, codes, ids, measures, slab_rows, path="auto"):
     out = {}
     for m in measures:
         near0, rew0 = eng.text_stats()
-        rec = {"pairs": n * (n - 1) // 2, "f64_bits_differ": 0, "naive_lines_differ": 0, "lines_differ": 0, "max_ulp": 0}
+        rec = {"pairs": n * (n - 1) // 2, "f64_bits_differ": 0, "naive_lines_differ": 0, "lines_differ": 0, "max_ulp": 0,
+               "max_abs_err": 0.0}
         for rb in range(0, n - 1, slab_rows):
             re = min(n - 1, rb + slab_rows)
             tl = eng.run_square(m, rb, re, tallies=True)
-            dev = eng.run_square(m, rb, re)
+            fast = eng.run_square(m, rb, re)
+            d_tl = torch.from_numpy(tl).cuda()
+            d_dev = torch.empty(len(tl), dtype=torch.float64, device="cuda")
+            eng.finalize_device(m, rb, re, d_tl.data_ptr(), d_dev.data_ptr(), d_dev.numel() * 8, tally_kind=da.OUT_TALLY, close=True)
+            dev = d_dev.cpu().numpy()
             host = oracle.finalize_square(m, tl, n, counts if m == "tn93" else None, rb, re, threads=THREADS)
+            both = np.isfinite(host) & np.isfinite(fast)
+            assert np.array_equal(np.isnan(host), np.isnan(fast)) and np.array_equal(np.isinf(host), np.isinf(fast)), m
+            assert np.array_equal(np.signbit(host[host == 0]), np.signbit(fast[host == 0])), m   # -0.0 stays -0.0
+            if both.any():
+                rec["max_abs_err"] = max(rec["max_abs_err"], float(np.abs(fast[both] - host[both]).max()))
             finite = np.isfinite(host) & np.isfinite(dev)
             assert np.array_equal(np.isnan(host), np.isnan(dev)) and np.array_equal(np.isinf(host), np.isinf(dev)), m
             differ = dev.view(np.uint64) != host.view(np.uint64)
@@ -109,6 +124,7 @@ def test_c2_whole_triangle_text_is_the_reference_text(eng):
     for m in LOGM:
         assert res[m]["lines_differ"] == 0, (m, res[m])
         assert res[m]["max_ulp"] <= 8, (m, res[m])          # the guard is 32-64 ulp
+        assert res[m]["max_abs_err"] <= 1e-12, (m, res[m])
         assert res[m]["rewritten"] >= res[m]["naive_lines_differ"], (m, res[m])
 
 
@@ -139,6 +155,7 @@ def test_every_distance_range_and_both_paths(eng, path):
         assert res[m]["path"] == path
         assert res[m]["lines_differ"] == 0, (m, res[m])
         assert res[m]["max_ulp"] <= 8, (m, res[m])
+        assert res[m]["max_abs_err"] <= 1e-12, (m, res[m])
         assert res[m]["near_ties"] > 0, (m, res[m])
 
 
