@@ -71,6 +71,7 @@ _SIGS = {
                                     C.c_size_t]),
     "dst_run_slabs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
     "dst_stream_open": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "dst_stream_open_wire": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)]),
     "dst_stream_acquire": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "dst_stream_submit": (C.c_int, [_vp, C.c_size_t, C.c_int]),
     "dst_stream_collect": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(_vp)]),
@@ -89,6 +90,7 @@ _SIGS = {
     "dst_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "dst_host_free": (C.c_int, [_vp]),
     "dst_out_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_uint64]),
+    "dst_kernel_ms_mean": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dst_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "dst_plan_tiles": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp,
                                  C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -36,6 +36,22 @@ int fail_hip(dst_ctx *ctx, hipError_t e, const char *what)
                 std::string(what) + ": " + hipGetErrorString(e));
 }
 
+int timer_begin(dst_ctx *ctx, int which, hipStream_t stream)
+{
+    dst_ctx::Timer &t = ctx->timer[which];
+    HIP_TRY(ctx, hipEventRecord(t.begin[t.seq % dst_ctx::kTimerRing], stream));
+    return DST_OK;
+}
+
+int timer_end(dst_ctx *ctx, int which, hipStream_t stream)
+{
+    dst_ctx::Timer &t = ctx->timer[which];
+    HIP_TRY(ctx, hipEventRecord(t.end[t.seq % dst_ctx::kTimerRing], stream));
+    t.seq += 1;
+    (which == 0 ? ctx->timed_pair : ctx->timed_pack) = true;
+    return DST_OK;
+}
+
 int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 {
     if (*have >= want)
@@ -73,7 +89,9 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     const size_t nchunks = std::max<size_t>(1, (len + kChunkSites - 1) / kChunkSites);
     const size_t npad = ((n + 256 + kPadRecords - 1) / kPadRecords) * kPadRecords;
     const size_t bytes = (size_t)PL_COUNT * nchunks * npad * sizeof(uint4);
-    if (!s.planes || !s.counts || s.planes_bytes < bytes || s.npad != npad || s.nchunks != nchunks) {
+    // (a set keeps the largest planes it ever needed: the batches of a stream differ in size, and hipFree would stall
+    // every stream of the device — the layout depends on npad and nchunks, the allocation only on their product)
+    if (!s.planes || !s.counts || s.planes_bytes < bytes || s.counts_cap < npad) {
         free_set(s);
         HIP_TRY(ctx, hipMalloc((void **)&s.planes, bytes ? bytes : 16));
         s.planes_bytes = bytes;
@@ -82,6 +100,7 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
             free_set(s);  // never leave a set with planes but no counts behind
             return fail_hip(ctx, e, "hipMalloc(base counts)");
         }
+        s.counts_cap = npad;
     }
     s.n = n;
     s.len = len;
@@ -126,8 +145,10 @@ int alloc_ref(dst_ctx *ctx, DeviceSet &s)
 // first and the pack counts every record's differences from it on the way (pre_cold / pre_hot), which is the
 // consensus path's first pass over the planes; the caller's one synchronisation then also brings the statistics.
 int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
-               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists)
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists, bool nibbles)
 {
+    if (nibbles)
+        want_lists = false;   // (the 4-bit wire format serves streamed batches: small row sets, lists built on demand)
     int rc = shape_set(ctx, s, n, len);
     if (rc)
         return rc;
@@ -153,10 +174,10 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
             const size_t cap = s.rec.pre_cap, pad = (2 * cap) & 1;
             s.rec.pre_hot = s.rec.pre_cold + cap;
             s.rec.pre_totals = reinterpret_cast<unsigned long long *>(s.rec.pre_cold + 2 * cap + pad);
-            HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (2 * cap + pad + 4) * sizeof(uint32_t), stream));
+            // (the pack's counts and first-invalid-byte cell are cleared on the sample's way: no fills of their own)
+            HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 2 * cap + pad + 4, d_first_bad));
+            HIP_TRY(ctx, launch_hot_list(s, stream));
         }
-        HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream));
-        HIP_TRY(ctx, launch_hot_list(s, stream));
         pl.ref_planes = s.ref.planes;
         pl.hot_planes = s.ref.hot_planes;
         pl.stats = reinterpret_cast<const unsigned long long *>(s.ref.stats);
@@ -165,13 +186,16 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         pl.cnt_hot = s.rec.pre_hot;
         pl.slots = s.rec.pre_slots;
     }
-    HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-    HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, want_lists ? &pl : nullptr, stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-    ctx->timed_pack = true;
-    if (want_lists)
-        HIP_TRY(ctx, launch_sum2_u32(s.rec.pre_cold, s.rec.pre_hot, n, s.rec.pre_totals, stream));
+    if (!want_lists)
+        HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
+    if (int rc_t = timer_begin(ctx, 1, stream))
+        return rc_t;
+    if (nibbles)
+        HIP_TRY(ctx, launch_pack_nibbles(d_codes, row_stride, s, d_first_bad, stream));
+    else
+        HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, d_first_bad, want_lists ? &pl : nullptr, stream));
+    if (int rc_t = timer_end(ctx, 1, stream))
+        return rc_t;
     if (d_counts) {
         HIP_TRY(ctx, hipMemsetAsync(s.counts, 0, s.npad * 4 * sizeof(uint32_t), stream));
         HIP_TRY(ctx, hipMemcpyAsync(s.counts, d_counts, n * 4 * sizeof(uint32_t),
@@ -206,7 +230,7 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     // the device writes its report (first invalid byte, statistics, totals) into page-locked host memory: one wait
     HIP_TRY(ctx, launch_report(ctx->d_first_bad,
                                want_lists ? reinterpret_cast<const unsigned long long *>(s.ref.stats) : nullptr,
-                               want_lists ? s.rec.pre_totals : nullptr, ctx->d_report, stream));
+                               want_lists ? s.rec.pre_cold : nullptr, want_lists ? s.rec.pre_hot : nullptr, n, ctx->d_report, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     const unsigned long long first_bad = ctx->h_report[0], totals[2] = {ctx->h_report[9], ctx->h_report[10]};
     if (want_lists)
@@ -501,7 +525,6 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     s.rec.ranges_valid = false;
     s.site.valid = false;
     uint32_t *d_ovf_n = reinterpret_cast<uint32_t *>(ctx->d_total + 1);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
     const uint4 *hot_planes = without_hot ? refset.ref.hot_planes : nullptr;
     unsigned long long total = 0;
     const uint32_t *scan_src0 = nullptr, *scan_src1 = nullptr;
@@ -516,6 +539,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         }
         scan_src0 = s.rec.pre_cold;
     } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(unsigned long long), stream));
         HIP_TRY(ctx, hipMemsetAsync(s.rec.off, 0, (s.n + 1) * sizeof(uint32_t), stream));
         HIP_TRY(ctx, launch_index(s, refset.ref.planes, hot_planes, false, false, s.rec.off, nullptr, ctx->d_total, stream));
         HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, stream));
@@ -533,7 +557,9 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
                           ((s.nchunks * kChunkSites + kBucketSites - 1) / kBucketSites) * s.npad * sizeof(uint32_t));
     if (rc)
         return rc;
-    HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream, scan_src0, scan_src1));
+    // (the scan also clears the counters behind it: [0..1] the list total of the count pass, [2..3] the overflow entries)
+    HIP_TRY(ctx, launch_exclusive_scan(s.rec.off, s.n + 1, ctx->scan_tmp, stream, scan_src0, scan_src1,
+                                       reinterpret_cast<uint32_t *>(ctx->d_total), 4));
     if (from_pack)   // the entries are in the pack's slots already
         HIP_TRY(ctx, launch_slot_fill(s, refset.ref.planes, refset.ref.hot_planes, without_hot, s.rec.off, s.rec.ent,
                                       want_sites ? s.rec.range_start : nullptr, stream));
@@ -815,10 +841,11 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         }
         ctx->last_path = path;
         if (ntiles) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+            if (int rc_t = timer_begin(ctx, 0, stream))
+                return rc_t;
             HIP_TRY(ctx, launch_consensus_pairs(measure, cl, f_words, stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-            ctx->timed_pair = true;
+            if (int rc_t = timer_end(ctx, 0, stream))
+                return rc_t;
             if (d_hot) {
                 HIP_TRY(ctx, hipEventRecord(ctx->hot_free, stream));
                 ctx->hot_used = true;
@@ -887,10 +914,11 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         }
     }
     if (nblocks) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+        if (int rc_t = timer_begin(ctx, 0, stream))
+            return rc_t;
         HIP_TRY(ctx, launch_pairs(measure, ctx->variant, pl, stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-        ctx->timed_pair = true;
+        if (int rc_t = timer_end(ctx, 0, stream))
+            return rc_t;
         if (ksplit > 1 && f64_out) {
             HIP_TRY(ctx, launch_finalize(measure, pl, ctx->scratch, false, d_out, stream));
             HIP_TRY(ctx, hipEventRecord(ctx->scratch_free, stream));
@@ -989,9 +1017,10 @@ int dst_create(int device, dst_ctx **out)
         return bail(c, e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail(c, e, "hipStreamCreate");
-    for (auto &ev : c->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess)
-            return bail(c, e, "hipEventCreate");
+    for (auto &t : c->timer)
+        for (int k = 0; k < dst_ctx::kTimerRing; ++k)
+            if ((e = hipEventCreate(&t.begin[k])) != hipSuccess || (e = hipEventCreate(&t.end[k])) != hipSuccess)
+                return bail(c, e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c->d_first_bad, sizeof(unsigned long long))) != hipSuccess)
         return bail(c, e, "hipMalloc");
     if ((e = hipHostMalloc((void **)&c->h_report, 16 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
@@ -1050,9 +1079,13 @@ int dst_destroy(dst_ctx *ctx)
         (void)hipFree(ctx->d_first_bad);
     if (ctx->h_report)
         (void)hipHostFree(ctx->h_report);
-    for (auto &ev : ctx->ev)
-        if (ev)
-            (void)hipEventDestroy(ev);
+    for (auto &t : ctx->timer)
+        for (int k = 0; k < dst_ctx::kTimerRing; ++k) {
+            if (t.begin[k])
+                (void)hipEventDestroy(t.begin[k]);
+            if (t.end[k])
+                (void)hipEventDestroy(t.end[k]);
+        }
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1546,12 +1579,14 @@ int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *
         return DST_ERR_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->timed_pair) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pair_ms, ctx->ev[0], ctx->ev[1]));
+        const int k = (int)((ctx->timer[0].seq - 1) % dst_ctx::kTimerRing);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->timer[0].end[k]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pair_ms, ctx->timer[0].begin[k], ctx->timer[0].end[k]));
     }
     if (ctx->timed_pack) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pack_ms, ctx->ev[2], ctx->ev[3]));
+        const int k = (int)((ctx->timer[1].seq - 1) % dst_ctx::kTimerRing);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->timer[1].end[k]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ctx->pack_ms, ctx->timer[1].begin[k], ctx->timer[1].end[k]));
     }
     if (pair_ms)
         *pair_ms = ctx->pair_ms;
@@ -1559,6 +1594,40 @@ int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *
         *finalize_ms = 0.0f;  // finalisation is fused into the pair kernel's epilogue
     if (pack_ms)
         *pack_ms = ctx->pack_ms;
+    return DST_OK;
+}
+
+int dst_kernel_ms_mean(dst_ctx *ctx, int reset, float *pair_ms, int *pair_launches, float *pack_ms, int *pack_launches)
+{
+    if (!ctx)
+        return DST_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float mean[2] = {0, 0};
+    int count[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+        dst_ctx::Timer &t = ctx->timer[w];
+        const uint64_t first = std::max(t.mark, t.seq > (uint64_t)dst_ctx::kTimerRing ? t.seq - dst_ctx::kTimerRing : 0);
+        double sum = 0;
+        for (uint64_t q = first; q < t.seq; ++q) {
+            const int k = (int)(q % dst_ctx::kTimerRing);
+            float ms = 0;
+            HIP_TRY(ctx, hipEventSynchronize(t.end[k]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.begin[k], t.end[k]));
+            sum += ms;
+        }
+        count[w] = (int)(t.seq - first);
+        mean[w] = count[w] ? (float)(sum / count[w]) : 0.0f;
+        if (reset)
+            t.mark = t.seq;
+    }
+    if (pair_ms)
+        *pair_ms = mean[0];
+    if (pair_launches)
+        *pair_launches = count[0];
+    if (pack_ms)
+        *pack_ms = mean[1];
+    if (pack_launches)
+        *pack_launches = count[1];
     return DST_OK;
 }
 

@@ -66,128 +66,6 @@ __device__ __forceinline__ uint32_t sample_record(uint32_t k, uint32_t n, uint32
     return samples == n ? k : k * (n >> 9) + ((k * (n & 511u)) >> 9);
 }
 
-// BYTES: the sample is read from the row-major code matrix itself (high nibble = the A,G,C,T plane bits), so the
-// reference exists BEFORE the pack and the pack can count every record's differences on its way (dst_kernels.hip).
-template <bool BYTES>
-__global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const uint32_t *__restrict__ planes32,
-                                                         const uint8_t *__restrict__ codes, size_t row_stride, uint32_t n,
-                                                         uint32_t len, uint32_t nchunks, uint32_t npad,
-                                                         uint32_t samples, uint4 *__restrict__ ref_planes,
-                                                         uint4 *__restrict__ hot_planes,
-                                                         uint32_t *__restrict__ partials)
-{
-    // GROUPS groups of 128 threads, thread = (site, every GROUPS-th sample), UNR sampled records per round: their
-    // loads are issued together (one record at a time this kernel was a chain of 128 memory latencies on one block
-    // per CU: 0.12 ms for 8 MB)
-    constexpr uint32_t GROUPS = BYTES ? 8 : 4, UNR = BYTES ? 16 : 8;
-    __shared__ uint32_t part[GROUPS][5][128];
-    const uint32_t c = blockIdx.x, b = threadIdx.x & 127u, grp = threadIdx.x >> 7;
-    const uint32_t w = b >> 5, bit = b & 31;
-    const size_t ps = (size_t)nchunks * npad * 4;  // plane stride in 32-bit words
-    uint32_t cnt[5] = {0, 0, 0, 0, 0};
-    for (uint32_t k0 = grp; k0 < samples; k0 += GROUPS * UNR) {
-        uint32_t nibs[UNR];
-        if constexpr (BYTES) {
-            uint32_t by[UNR];
-            const uint32_t site = c * kChunkSites + b;
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; ++u) {
-                const uint32_t k = k0 + GROUPS * u;
-                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
-                by[u] = site < len ? codes[(size_t)r * row_stride + site] : 0xF0u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; ++u)
-                nibs[u] = by[u] >> 4;
-        } else {
-            uint32_t pw[UNR][4];
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; ++u) {
-                const uint32_t k = k0 + GROUPS * u;
-                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
-                const size_t at = ((size_t)c * npad + r) * 4 + w;
-                pw[u][0] = planes32[PL_A * ps + at];
-                pw[u][1] = planes32[PL_G * ps + at];
-                pw[u][2] = planes32[PL_C * ps + at];
-                pw[u][3] = planes32[PL_T * ps + at];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; ++u)
-                nibs[u] = ((pw[u][0] >> bit) & 1u) << 3 | ((pw[u][1] >> bit) & 1u) << 2 |
-                          ((pw[u][2] >> bit) & 1u) << 1 | ((pw[u][3] >> bit) & 1u);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < UNR; ++u) {
-            if (k0 + GROUPS * u >= samples)
-                break;
-            const uint32_t nib = nibs[u];
-            cnt[0] += nib == 8;
-            cnt[1] += nib == 4;
-            cnt[2] += nib == 2;
-            cnt[3] += nib == 1;
-            cnt[4] += nib == 15;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-        part[grp][k][b] = cnt[k];
-    __syncthreads();
-    if (grp != 0)
-        return;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        cnt[k] = 0;
-#pragma unroll
-        for (uint32_t g = 0; g < GROUPS; ++g)
-            cnt[k] += part[g][k][b];
-    }
-    uint32_t best = cnt[0], cls = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < 5; ++k)
-        if (cnt[k] > best) {
-            best = cnt[k];
-            cls = k;
-        }
-    const uint32_t site = c * kChunkSites + b;
-    const bool real = site < len;
-    const uint32_t nib = !real ? 15u : cls == 0 ? 8u : cls == 1 ? 4u : cls == 2 ? 2u : cls == 3 ? 1u : 15u;
-    const uint32_t wave = b >> 6;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const unsigned long long m = __ballot((nib >> (3 - p)) & 1u);
-        if ((b & 63) == 0)
-            reinterpret_cast<unsigned long long *>(&ref_planes[(size_t)p * nchunks + c])[wave] = m;
-    }
-    // "hot" sites: more than kHotPermille of the sampled records deviate from the plurality (clade-defining
-    // mutations, indel-rich columns).  Their events grow with p^2; the hybrid path gives these columns to the
-    // dense kernels instead (dst_api.cpp) and keeps them out of the lists.
-    const uint32_t devs = real ? samples - best : 0u;
-    const bool hot = devs * 1000u > samples * kHotPermille;
-    const unsigned long long hot_mask = __ballot(hot);
-    if ((b & 63) == 0)
-        reinterpret_cast<unsigned long long *>(&hot_planes[c])[wave] = hot_mask;
-    // statistics for the path choice: known reference sites, sum and sum of squares of the sampled
-    // records that deviate from the plurality class — over all sites and over the cold ones alone
-    const unsigned long long known = __ballot(real && cls < 4);
-    const unsigned long long known_hot = __ballot(real && cls < 4 && hot);
-    uint32_t dev = devs, dev2 = devs * devs, cdev = hot ? 0u : devs, cdev2 = hot ? 0u : devs * devs;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        dev += __shfl_xor(dev, o);
-        dev2 += __shfl_xor(dev2, o);
-        cdev += __shfl_xor(cdev, o);
-        cdev2 += __shfl_xor(cdev2, o);
-    }
-    // this wave's share of the statistics (two per chunk, summed by hot_list_kernel: no same-address atomics)
-    if ((b & 63u) == 0) {
-        const uint32_t mine[8] = {(uint32_t)__builtin_popcountll(known), dev, dev2, 0u, (uint32_t)__builtin_popcountll(hot_mask),
-                                  (uint32_t)__builtin_popcountll(known_hot), cdev, cdev2};
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            partials[((size_t)c * 2 + wave) * 8 + k] = mine[k];
-    }
-}
-
 // ascending list of the hot sites (one block; nchunks is at most a few ten thousand)
 __global__ __launch_bounds__(1024) void hot_list_kernel(const uint4 *__restrict__ hot_planes, uint32_t nchunks,
                                                         uint32_t *__restrict__ hot_sites,
@@ -255,6 +133,140 @@ __global__ __launch_bounds__(1024) void hot_list_kernel(const uint4 *__restrict_
             base += total;
         __syncthreads();
     }
+}
+
+// BYTES: the sample is read from the row-major code matrix itself (high nibble = the A,G,C,T plane bits), so the
+// reference exists BEFORE the pack and the pack can count every record's differences on its way (dst_kernels.hip).
+template <bool BYTES>
+__global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const uint32_t *__restrict__ planes32,
+                                                         const uint8_t *__restrict__ codes, size_t row_stride, uint32_t n,
+                                                         uint32_t len, uint32_t nchunks, uint32_t npad,
+                                                         uint32_t samples, uint4 *__restrict__ ref_planes,
+                                                         uint4 *__restrict__ hot_planes,
+                                                         uint32_t *__restrict__ partials,
+                                                         uint32_t *__restrict__ zero, uint32_t zero_words,
+                                                         unsigned long long *__restrict__ first_bad)
+{
+    // what the pack behind this kernel adds to / takes the minimum of, cleared here instead of by two fills of their own
+    if constexpr (BYTES) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x)
+            zero[i] = 0;
+        if (first_bad && blockIdx.x == 0 && threadIdx.x == 0)
+            *first_bad = ~0ull;
+    }
+    // GROUPS groups of 128 threads, thread = (site, every GROUPS-th sample), UNR sampled records per round: their
+    // loads are issued together (one record at a time this kernel was a chain of 128 memory latencies on one block
+    // per CU: 0.12 ms for 8 MB)
+    constexpr uint32_t GROUPS = BYTES ? 8 : 4, UNR = BYTES ? 16 : 8;
+    __shared__ uint32_t part[GROUPS][5][128];
+    const uint32_t c = blockIdx.x, b = threadIdx.x & 127u, grp = threadIdx.x >> 7;
+    const uint32_t w = b >> 5, bit = b & 31;
+    const size_t ps = (size_t)nchunks * npad * 4;  // plane stride in 32-bit words
+    uint32_t cnt[5] = {0, 0, 0, 0, 0};
+    for (uint32_t k0 = grp; k0 < samples; k0 += GROUPS * UNR) {
+        uint32_t nibs[UNR];
+        if constexpr (BYTES) {
+            uint32_t by[UNR];
+            const uint32_t site = c * kChunkSites + b;
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u) {
+                const uint32_t k = k0 + GROUPS * u;
+                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
+                by[u] = site < len ? codes[(size_t)r * row_stride + site] : 0xF0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u)
+                nibs[u] = by[u] >> 4;
+        } else {
+            uint32_t pw[UNR][4];
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u) {
+                const uint32_t k = k0 + GROUPS * u;
+                const uint32_t r = sample_record(min(k, samples - 1), n, samples);
+                const size_t at = ((size_t)c * npad + r) * 4 + w;
+                pw[u][0] = planes32[PL_A * ps + at];
+                pw[u][1] = planes32[PL_G * ps + at];
+                pw[u][2] = planes32[PL_C * ps + at];
+                pw[u][3] = planes32[PL_T * ps + at];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; ++u)
+                nibs[u] = ((pw[u][0] >> bit) & 1u) << 3 | ((pw[u][1] >> bit) & 1u) << 2 |
+                          ((pw[u][2] >> bit) & 1u) << 1 | ((pw[u][3] >> bit) & 1u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; ++u) {
+            if (k0 + GROUPS * u >= samples)
+                break;
+            const uint32_t nib = nibs[u];
+            cnt[0] += nib == 8;
+            cnt[1] += nib == 4;
+            cnt[2] += nib == 2;
+            cnt[3] += nib == 1;
+            cnt[4] += nib == 15;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        part[grp][k][b] = cnt[k];
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        cnt[k] = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < GROUPS; ++g)
+            cnt[k] += part[g][k][b];
+    }
+    uint32_t best = cnt[0], cls = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 5; ++k)
+        if (cnt[k] > best) {
+            best = cnt[k];
+            cls = k;
+        }
+    const uint32_t site = c * kChunkSites + b;
+    const bool real = site < len;
+    const uint32_t nib = !real ? 15u : cls == 0 ? 8u : cls == 1 ? 4u : cls == 2 ? 2u : cls == 3 ? 1u : 15u;
+    const uint32_t wave = b >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned long long m = __ballot((nib >> (3 - p)) & 1u);
+        if ((b & 63) == 0)
+            reinterpret_cast<unsigned long long *>(&ref_planes[(size_t)p * nchunks + c])[wave] = m;
+    }
+    // "hot" sites: more than kHotPermille of the sampled records deviate from the plurality (clade-defining
+    // mutations, indel-rich columns).  Their events grow with p^2; the hybrid path gives these columns to the
+    // dense kernels instead (dst_api.cpp) and keeps them out of the lists.
+    const uint32_t devs = real ? samples - best : 0u;
+    const bool hot = devs * 1000u > samples * kHotPermille;
+    const unsigned long long hot_mask = __ballot(hot);
+    if ((b & 63) == 0)
+        reinterpret_cast<unsigned long long *>(&hot_planes[c])[wave] = hot_mask;
+    // statistics for the path choice: known reference sites, sum and sum of squares of the sampled
+    // records that deviate from the plurality class — over all sites and over the cold ones alone
+    const unsigned long long known = __ballot(real && cls < 4);
+    const unsigned long long known_hot = __ballot(real && cls < 4 && hot);
+    uint32_t dev = devs, dev2 = devs * devs, cdev = hot ? 0u : devs, cdev2 = hot ? 0u : devs * devs;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dev += __shfl_xor(dev, o);
+        dev2 += __shfl_xor(dev2, o);
+        cdev += __shfl_xor(cdev, o);
+        cdev2 += __shfl_xor(cdev2, o);
+    }
+    // this wave's share of the statistics (two per chunk, summed by hot_list_kernel: no same-address atomics)
+    if ((b & 63u) == 0) {
+        const uint32_t mine[8] = {(uint32_t)__builtin_popcountll(known), dev, dev2, 0u, (uint32_t)__builtin_popcountll(hot_mask),
+                                  (uint32_t)__builtin_popcountll(known_hot), cdev, cdev2};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            partials[((size_t)c * 2 + wave) * 8 + k] = mine[k];
+    }
+    }   // grp == 0
+    // (measured and not kept: the statistics' sum and the hot-site list as the tail of whichever block finishes last —
+    // the agent-scope fences that needs, an L2 write-back per block on this multi-die part, cost 60 us against the
+    // 13 us of hot_list_kernel as a launch of its own)
 }
 
 // The hot columns of a set as a packed set of their own (all 8 planes): one thread = one (record, chunk of 128
@@ -775,6 +787,67 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
             data[base + k] += off;
 }
 
+// The same for up to kScanSmallMax elements in ONE launch (a 10,000-record step is a dozen short kernels: the three
+// launches of the general scan and the memset before it were 25 us of its 420): one block walks the array in pieces of
+// 4,096 with a running carry.  zero[0..n_zero) is cleared on the way (the counters the next kernels add to).
+constexpr size_t kScanSmallMax = 65536;
+__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__ data, uint32_t n, const uint32_t *__restrict__ src0,
+                                                          const uint32_t *__restrict__ src1, uint32_t *__restrict__ zero,
+                                                          uint32_t n_zero)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid < n_zero)
+        zero[tid] = 0;
+    if (tid == 0)
+        carry_s = 0;
+    __syncthreads();
+    auto load4 = [&](uint32_t at, uint32_t (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = at + k < n ? (src0 ? src0[at + k] + (src1 ? src1[at + k] : 0u) : data[at + k]) : 0u;
+    };
+    uint32_t nx[4];
+    load4(4 * tid, nx);
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t at = base + 4 * tid;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = nx[k];
+            sum += v[k];
+        }
+        if (base + 4096 < n)
+            load4(at + 4096, nx);   // the next piece is on its way while this one is scanned
+        uint32_t incl = sum, up;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            up = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += up;
+        }
+        if (lane == 63u)
+            wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t off = carry_s, total = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wv) off += wave_tot[w];
+            total += wave_tot[w];
+        }
+        uint32_t run = off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (at + k < n)
+                data[at + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 0)
+            carry_s += total;
+        __syncthreads();
+    }
+}
+
 // totals[k] += sum of a[k][0..n) for the two count arrays of the pack (totals zeroed by the caller)
 __global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restrict__ a0, const uint32_t *__restrict__ a1, size_t n,
                                                        unsigned long long *__restrict__ totals)
@@ -805,17 +878,50 @@ __global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restric
 
 // What the host wants to know after an upload, gathered into one page-locked host block by the device itself (three
 // blocking device-to-host copies of 8-64 bytes cost ~20 us each: a fifth of a 10,000-record step)
-__global__ __launch_bounds__(64) void report_kernel(const unsigned long long *__restrict__ first_bad,
-                                                    const unsigned long long *__restrict__ stats,
-                                                    const unsigned long long *__restrict__ totals, unsigned long long *report)
+__global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *__restrict__ first_bad,
+                                                      const unsigned long long *__restrict__ stats,
+                                                      const uint32_t *__restrict__ cnt0, const uint32_t *__restrict__ cnt1, uint32_t n,
+                                                      unsigned long long *report)
 {
+    // the list totals: the pack's two count arrays summed here (a kernel of their own they were one more launch)
+    __shared__ unsigned long long part[16][2];
+    unsigned long long s0 = 0, s1 = 0;
+    if (cnt0)
+        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {   // 16 loads in flight per thread: one block, latency-bound
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + 1024 * u;
+                a[u] = i < n ? cnt0[i] : 0u;
+                b[u] = i < n ? cnt1[i] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                s0 += a[u];
+                s1 += b[u];
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        part[threadIdx.x >> 6][0] = s0;
+        part[threadIdx.x >> 6][1] = s1;
+    }
+    __syncthreads();
     const uint32_t t = threadIdx.x;
     if (t == 0)
         report[0] = *first_bad;
     else if (t <= 8)
         report[t] = stats ? stats[t - 1] : 0ull;
-    else if (t < (uint32_t)kReportWords)
-        report[t] = totals ? totals[t - 9] : 0ull;
+    else if (t < (uint32_t)kReportWords) {
+        unsigned long long sum = 0;
+        for (int w = 0; w < 16; ++w)
+            sum += part[w][t - 9];
+        report[t] = sum;
+    }
 }
 
 // =============================================================================================
@@ -1691,16 +1797,17 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
     hipLaunchKernelGGL(ref_sample_kernel<false>, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), nullptr, 0, (uint32_t)set.n, (uint32_t)set.len,
                        (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes, set.ref.hot_planes,
-                       set.ref.partials);
+                       set.ref.partials, nullptr, 0u, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream)
+hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream,
+                                   uint32_t *zero, size_t zero_words, unsigned long long *first_bad)
 {
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, kRefSamples);
     hipLaunchKernelGGL(ref_sample_kernel<true>, dim3((unsigned)set.nchunks), dim3(1024), 0, stream, nullptr, d_codes, row_stride,
                        (uint32_t)set.n, (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
-                       set.ref.hot_planes, set.ref.partials);
+                       set.ref.hot_planes, set.ref.partials, zero, (uint32_t)zero_words, first_bad);
     return hipGetLastError();
 }
 
@@ -1784,10 +1891,19 @@ size_t scan_tmp_words(size_t n)
 }
 
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0,
-                                 const uint32_t *src1)
+                                 const uint32_t *src1, uint32_t *zero, uint32_t n_zero)
 {
-    if (n == 0)
+    if (n == 0 && !n_zero)
         return hipSuccess;
+    if (n <= kScanSmallMax) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, data, (uint32_t)n, src0, src1, zero, zero ? n_zero : 0u);
+        return hipGetLastError();
+    }
+    if (zero && n_zero) {
+        const hipError_t ez = hipMemsetAsync(zero, 0, n_zero * sizeof(uint32_t), stream);
+        if (ez != hipSuccess)
+            return ez;
+    }
     const size_t nb = (n + kScanPerBlock - 1) / kScanPerBlock;
     hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, stream, data, n, tmp, src0, src1);
     hipError_t e = hipGetLastError();
@@ -1806,10 +1922,10 @@ hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, uns
     return hipGetLastError();
 }
 
-hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const unsigned long long *totals,
-                         unsigned long long *report, hipStream_t stream)
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const uint32_t *cnt_cold,
+                         const uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream)
 {
-    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, first_bad, stats, totals, report);
+    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(1024), 0, stream, first_bad, stats, cnt_cold, cnt_hot, (uint32_t)n, report);
     return hipGetLastError();
 }
 

@@ -91,7 +91,14 @@ struct dst_ctx {
         uint64_t last_biggest = 0;   // entries of the largest block of the previous shared upload (sizes the next one)
         uint64_t uploads = 0, fallbacks = 0;
     } shared[2];
-    hipEvent_t ev[4] = {};  // pair kernel start/end, pack kernel start/end
+    // HIP events around the pair kernel ([0]) and the pack kernel ([1]) of the most recent launches, recorded on the launch
+    // stream: a ring, so that a caller timing many steps reads them ONCE at the end (dst_kernel_ms_mean) instead of
+    // waiting for the device after every step
+    static constexpr int kTimerRing = 64;
+    struct Timer {
+        hipEvent_t begin[kTimerRing] = {}, end[kTimerRing] = {};
+        uint64_t seq = 0, mark = 0;   // launches timed so far; where the running mean starts
+    } timer[2];
     float pair_ms = 0, pack_ms = 0;
     bool timed_pair = false, timed_pack = false;
     std::string err;
@@ -106,6 +113,9 @@ namespace dst {
 constexpr double kListsMaxDeviation = 0.08;
 
 int fail(dst_ctx *ctx, int status, const std::string &msg);
+// bracket the next pair (which = 0) / pack (1) kernel on `stream` with the timer ring's events
+int timer_begin(dst_ctx *ctx, int which, hipStream_t stream);
+int timer_end(dst_ctx *ctx, int which, hipStream_t stream);
 int fail_hip(dst_ctx *ctx, hipError_t e, const char *what);
 
 #define HIP_TRY(ctx, call)                       \
@@ -119,8 +129,9 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want);
 void free_set(DeviceSet &s);
 // queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the index of the first
 // byte that is not a Paradis code (or stays ~0).  Nothing here waits for the device.
+// nibbles: d_codes holds the 4-bit wire format (two sites per byte) instead of Paradis bytes
 int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, size_t len, size_t row_stride,
-               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists);
+               const uint32_t *d_counts, unsigned long long *d_first_bad, hipStream_t stream, bool want_lists, bool nibbles = false);
 int invalid_code_error(dst_ctx *ctx, unsigned long long first_bad, size_t len);
 // the per-record {A,T,G,C} counts of `s` on the device (counted by code unless the upload brought them)
 int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream);

@@ -113,7 +113,7 @@ struct SiteIndex {                // the same entries of a column set by (site, 
 struct DeviceSet {
     uint4 *planes = nullptr;      // PL_COUNT * nchunks * npad
     uint32_t *counts = nullptr;   // npad x 4 {A,T,G,C}
-    size_t planes_bytes = 0;
+    size_t planes_bytes = 0, counts_cap = 0;   // what the two allocations hold (bytes; records)
     size_t n = 0, len = 0, nchunks = 0, npad = 0;
     bool loaded = false;
     bool have_counts = false;
@@ -223,7 +223,9 @@ hipError_t launch_shared_splice(const uint32_t *gathered, const SharedLayout &la
                                 uint32_t *scan_tmp, bool with_counts, unsigned long long *report, hipStream_t stream);
 hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream);
 // the same from the row-major code matrix (before the pack)
-hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream);
+// ... on its way the kernel clears zero[0..zero_words) and sets *first_bad = ~0: what the pack behind it accumulates into
+hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set, hipStream_t stream,
+                                   uint32_t *zero = nullptr, size_t zero_words = 0, unsigned long long *first_bad = nullptr);
 // count pass (fill == false): rec_cnt[n], site_cnt[len * n_panels] (when want_sites), *total
 // fill pass: entries behind the scanned offsets.  ref_planes: [4][nchunks] uint4.
 hipError_t launch_hot_list(const DeviceSet &set, hipStream_t stream);
@@ -244,12 +246,14 @@ hipError_t launch_site_buckets(const DeviceSet &set, uint32_t n_panels, uint32_t
 // in-place exclusive scan of data[0..n) (data[n] receives the total); tmp: scan_tmp_words(n) words
 size_t scan_tmp_words(size_t n);
 // exclusive scan of data[0..n) in place; src0 (+ src1) given: of src0[i] (+ src1[i]) into data
+// zero[0..n_zero) (n_zero <= 1024) is cleared before the scan's results are visible: counters the next kernels add to
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0 = nullptr,
-                                 const uint32_t *src1 = nullptr);
+                                 const uint32_t *src1 = nullptr, uint32_t *zero = nullptr, uint32_t n_zero = 0);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
 constexpr int kReportWords = 11;   // [0] first invalid byte, [1..8] the sample's statistics, [9..10] list totals
-hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const unsigned long long *totals,
-                         unsigned long long *report, hipStream_t stream);
+// cnt_cold / cnt_hot (may be NULL): the pack's list lengths, summed into words 9 and 10
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const uint32_t *cnt_cold,
+                         const uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream);
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
@@ -272,6 +276,10 @@ struct PackLists {
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream, size_t rec_begin = 0,
                        size_t rec_end = ~(size_t)0);
+// the 4-bit wire format: rows of ceil(len / 2) bytes (row_stride a multiple of 64, base 16-byte aligned), two sites per
+// byte, even site in the low nibble, a site = the high nibble of its Paradis code
+hipError_t launch_pack_nibbles(const uint8_t *d_nibbles, size_t row_stride, const DeviceSet &set, unsigned long long *d_first_bad,
+                               hipStream_t stream);
 hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
 // the counts of records [rec_begin, rec_end) only, out[0..4) = record rec_begin's
 hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream);

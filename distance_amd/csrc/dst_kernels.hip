@@ -226,6 +226,75 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
             planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
+// The same from the 4-bit wire format of the stream pipeline (dst_stream_open_wire, DST_WIRE_NIBBLES): a site is the
+// high nibble of its Paradis code — all that any measure reads (bit 3 of the code, "known", is "exactly one base") —
+// two sites per byte, the even site in the low nibble.  Half the bytes over the host link, which is what bounds a
+// streamed job (1,000 x 5 Mbp loaded vs streamed batches: 320 MB per 64-record batch at 8 bits).  One thread = one
+// (record, 128-site chunk) = 64 bytes of input; nibble 0 (no base) is not a code.
+template <int BIT>   // plane bit within the nibble: 3 = A, 2 = G, 1 = C, 0 = T
+__device__ __forceinline__ uint32_t gather_nibbles(uint32_t x)   // 8 sites of one 32-bit word -> 8 plane bits
+{
+    const uint32_t even = __builtin_amdgcn_udot4((x >> BIT) & 0x01010101u, 0x40100401u, 0u, false);
+    return __builtin_amdgcn_udot4((x >> (BIT + 4)) & 0x01010101u, 0x80200802u, even, false);
+}
+
+__global__ __launch_bounds__(256) void pack_nibbles_kernel(const uint8_t *__restrict__ nibbles, size_t row_stride, uint32_t n,
+                                                           uint32_t len, uint32_t nchunks, uint32_t npad,
+                                                           uint4 *__restrict__ planes,
+                                                           unsigned long long *__restrict__ first_bad)
+{
+    const uint32_t s = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (s >= npad)
+        return;
+    uint32_t out[PL_COUNT][4];
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            out[p][w] = (p <= PL_T) ? 0xFFFFFFFFu : 0u;  // all N
+    if (s < n) {
+        const uint32_t site0 = c * kChunkSites;
+        const uint4 *row = reinterpret_cast<const uint4 *>(nibbles + (size_t)s * row_stride + site0 / 2);
+        uint4 in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            in[k] = row[k];
+        uint32_t bad_at = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t x[4] = {in[w].x, in[w].y, in[w].z, in[w].w};
+            uint32_t A = 0, G = 0, C = 0, T = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t first = site0 + 32u * w + 8u * g;
+                if (first + 8 > len) {   // the row's last word: what lies past its end becomes N
+                    const uint32_t keep = first < len ? len - first : 0u;
+                    const uint32_t m = keep ? 0xFFFFFFFFu >> (32u - 4u * keep) : 0u;
+                    x[g] = (x[g] & m) | ~m;
+                }
+                const uint32_t zero = (x[g] - 0x11111111u) & ~x[g] & 0x88888888u;   // some nibble is 0 (the lowest mark is exact)
+                if (zero && bad_at == 0xFFFFFFFFu)
+                    bad_at = 32u * w + 8u * g + ((uint32_t)__builtin_ctz(zero) >> 2);
+                A |= gather_nibbles<3>(x[g]) << (8 * g);
+                G |= gather_nibbles<2>(x[g]) << (8 * g);
+                C |= gather_nibbles<1>(x[g]) << (8 * g);
+                T |= gather_nibbles<0>(x[g]) << (8 * g);
+            }
+            out[PL_A][w] = A;
+            out[PL_G][w] = G;
+            out[PL_C][w] = C;
+            out[PL_T][w] = T;
+            derive_planes(A, G, C, T, out[PL_K][w], out[PL_X1][w], out[PL_X0][w], out[PL_CL][w]);
+        }
+        if (bad_at != 0xFFFFFFFFu)
+            atomicMin(first_bad, (unsigned long long)s * len + site0 + bad_at);
+    }
+#pragma unroll
+    for (int p = 0; p < PL_COUNT; ++p)
+        planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+}
+
 // the four derived planes of a set that was packed lean
 __global__ __launch_bounds__(256) void derive_kernel(uint4 *__restrict__ planes, size_t per_plane)
 {
@@ -673,6 +742,15 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
                        d_first_bad, aligned16, lists ? *lists : none, first, last);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_nibbles(const uint8_t *d_nibbles, size_t row_stride, const DeviceSet &set, unsigned long long *d_first_bad,
+                               hipStream_t stream)
+{
+    dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
+    hipLaunchKernelGGL(pack_nibbles_kernel, grid, dim3(256), 0, stream, d_nibbles, row_stride, (uint32_t)set.n, (uint32_t)set.len,
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes, d_first_bad);
     return hipGetLastError();
 }
 

@@ -118,8 +118,9 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     if (rc)
         return rc;
     // ---- this rank's share: reference from the bytes, pack + count, scan, lists straight into the block
-    HIP_TRY(ctx, hipMemsetAsync(s.rec.pre_cold, 0, (2 * s.rec.pre_cap + ((2 * s.rec.pre_cap) & 1) + 4) * sizeof(uint32_t), stream));
-    HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream));
+    // (the pack's counts and first-invalid-byte cell are cleared on the sample's way: no fills of their own)
+    HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 2 * s.rec.pre_cap + ((2 * s.rec.pre_cap) & 1) + 4,
+                                         ctx->d_first_bad));
     HIP_TRY(ctx, launch_hot_list(s, stream));
     PackLists pl{};
     pl.ref_planes = s.ref.planes;
@@ -129,11 +130,13 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     pl.cnt_cold = s.rec.pre_cold;
     pl.cnt_hot = s.rec.pre_hot;
     pl.slots = s.rec.pre_slots;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_bad, 0xFF, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+    rc = timer_begin(ctx, 1, stream);
+    if (rc)
+        return rc;
     HIP_TRY(ctx, launch_pack(d_codes, row_stride, s, ctx->d_first_bad, &pl, stream, rec_begin, rec_end));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-    ctx->timed_pack = true;
+    rc = timer_end(ctx, 1, stream);
+    if (rc)
+        return rc;
     uint32_t *block = static_cast<uint32_t *>(sh.send);
     HIP_TRY(ctx, launch_exclusive_scan(sh.off_local, count + 1, ctx->scan_tmp, stream, s.rec.pre_cold + rec_begin, s.rec.pre_hot + rec_begin));
     HIP_TRY(ctx, launch_shared_block(block, lay, s, rec_begin, count, sh.off_local, ctx->d_first_bad, stream));

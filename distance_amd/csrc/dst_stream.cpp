@@ -21,7 +21,7 @@ using namespace dst;
 
 struct dst_stream {
     dst_ctx *ctx = nullptr;
-    int measure = 0, out_kind = 0;
+    int measure = 0, out_kind = 0, wire = DST_WIRE_CODES;
     size_t max_records = 0, len = 0, pitch = 0;
     size_t out_bytes_per_record = 0;
     struct Slot {
@@ -75,9 +75,16 @@ extern "C" {
 
 int dst_stream_open(dst_ctx *ctx, int measure, int out_kind, size_t max_records, int depth, dst_stream **out)
 {
+    return dst_stream_open_wire(ctx, measure, out_kind, max_records, depth, DST_WIRE_CODES, out);
+}
+
+int dst_stream_open_wire(dst_ctx *ctx, int measure, int out_kind, size_t max_records, int depth, int wire, dst_stream **out)
+{
     if (!ctx || !out)
         return DST_ERR_ARG;
     *out = nullptr;
+    if (wire != DST_WIRE_CODES && wire != DST_WIRE_NIBBLES)
+        return fail(ctx, DST_ERR_ARG, "unknown wire format");
     if (measure < DST_N || measure > DST_TN93)
         return fail(ctx, DST_ERR_ARG, "unknown measure");
     if (out_kind != DST_OUT_DISTANCE && out_kind != DST_OUT_TALLY)
@@ -96,7 +103,10 @@ int dst_stream_open(dst_ctx *ctx, int measure, int out_kind, size_t max_records,
     s->out_kind = out_kind;
     s->max_records = max_records;
     s->len = loaded.len;
-    s->pitch = std::max<size_t>(((loaded.len + 127) / 128) * 128, 128);
+    s->wire = wire;
+    // rows 128 bytes apart at least: whole 128-site chunks of input per row (64 bytes of nibbles, 128 of codes)
+    s->pitch = wire == DST_WIRE_NIBBLES ? std::max<size_t>(((((loaded.len + 127) / 128) * 64 + 127) / 128) * 128, 128)
+                                        : std::max<size_t>(((loaded.len + 127) / 128) * 128, 128);
     s->out_bytes_per_record = dst_out_bytes(measure, out_kind, loaded.n);
     s->slots.resize((size_t)depth);
     hipError_t e = hipStreamCreateWithFlags(&s->s_in, hipStreamNonBlocking);
@@ -170,7 +180,7 @@ int dst_stream_submit(dst_stream *s, size_t n_records, int use_base_counts)
     HIP_TRY(ctx, hipStreamWaitEvent(s->s_compute, sl.h2d, 0));
     int rc = pack_queue(ctx, sl.set, sl.d_in, n_records, s->len, s->pitch,
                         use_base_counts ? reinterpret_cast<const uint32_t *>(sl.d_in + counts_offset(s)) : nullptr,
-                        sl.d_bad, s->s_compute, false);
+                        sl.d_bad, s->s_compute, false, s->wire == DST_WIRE_NIBBLES);
     if (rc)
         return rc;
     sl.set.loaded = true;  // validity is reported by dst_stream_collect

@@ -267,9 +267,10 @@ class Engine:
         self.upload(1, batch_codes, batch_counts)
         return self.run_rect(measure, row_slot=1, col_slot=0, tallies=tallies)
 
-    def stream(self, measure, max_records: int, depth: int = 3, tallies: bool = False) -> "Stream":
-        """The overlapped stream-mode pipeline (dst_stream_*): batches against the loaded set of slot 0."""
-        return Stream(self, measure, max_records, depth, tallies)
+    def stream(self, measure, max_records: int, depth: int = 3, tallies: bool = False, nibbles: bool = False) -> "Stream":
+        """The overlapped stream-mode pipeline (dst_stream_*): batches against the loaded set of slot 0.
+        nibbles: the 4-bit wire format (DST_WIRE_NIBBLES): push() packs the codes' high nibbles, two sites per byte."""
+        return Stream(self, measure, max_records, depth, tallies, nibbles)
 
     def run_slabs(self, measure, sink, max_pairs: int, square: bool = True, row_slot: int = 0, col_slot: int = 1,
                   tallies: bool = False):
@@ -351,6 +352,13 @@ class Engine:
         self._check(self._lib.dst_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"pair_ms": a.value, "finalize_ms": b.value, "pack_ms": c.value}
 
+    def kernel_ms_mean(self, reset: bool = True) -> dict:
+        """Mean pair / pack kernel time over the launches since the last reset (HIP events on the launch stream, read once:
+        dst_kernel_ms_mean)."""
+        a, b, na, nb = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+        self._check(self._lib.dst_kernel_ms_mean(self._h, int(reset), C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return {"pair_ms": a.value, "pair_launches": na.value, "pack_ms": b.value, "pack_launches": nb.value}
+
     def out_bytes(self, measure, pairs: int, tallies: bool = False) -> int:
         return int(self._lib.dst_out_bytes(_measure_id(measure), OUT_TALLY if tallies else OUT_DISTANCE,
                                            pairs))
@@ -415,14 +423,15 @@ class Stream:
     overlapped.  push() copies a batch into the acquired buffer and submits it; pop() returns the oldest batch's
     results [streamed record][loaded record] (a copy)."""
 
-    def __init__(self, eng: Engine, measure, max_records: int, depth: int, tallies: bool):
+    def __init__(self, eng: Engine, measure, max_records: int, depth: int, tallies: bool, nibbles: bool = False):
         self._eng, self._lib = eng, eng._lib
+        self.nibbles = nibbles
         self._m = _measure_id(measure)
         self._kind = OUT_TALLY if tallies else OUT_DISTANCE
         self._n_loaded, self._len = eng.set_info(0)
         self.max_records, self.depth = max_records, depth
         h = C.c_void_p()
-        eng._check(self._lib.dst_stream_open(eng._h, self._m, self._kind, max_records, depth, C.byref(h)))
+        eng._check(self._lib.dst_stream_open_wire(eng._h, self._m, self._kind, max_records, depth, int(nibbles), C.byref(h)))
         self._h = h
 
     def buffer(self):
@@ -431,14 +440,22 @@ class Stream:
         self._eng._check(self._lib.dst_stream_acquire(self._h, C.byref(p), C.byref(pitch), C.byref(cnt)))
         raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.max_records, pitch.value))
         counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_uint32)), shape=(self.max_records, 4))
-        return raw[:, :self._len], counts
+        return raw[:, :((self._len + 1) // 2 if self.nibbles else self._len)], counts
 
     def submit(self, n_records: int, use_counts: bool = False):
         self._eng._check(self._lib.dst_stream_submit(self._h, n_records, int(use_counts)))
 
+    @staticmethod
+    def to_nibbles(codes: np.ndarray) -> np.ndarray:
+        """Paradis codes (n, L) -> the 4-bit wire format (n, ceil(L / 2)): site 2k in the low nibble of byte k"""
+        hi = np.ascontiguousarray(codes, np.uint8) >> 4
+        if hi.shape[1] % 2:
+            hi = np.concatenate([hi, np.full((hi.shape[0], 1), 15, np.uint8)], axis=1)
+        return hi[:, 0::2] | (hi[:, 1::2] << 4)
+
     def push(self, codes: np.ndarray, counts=None):
         buf, cbuf = self.buffer()
-        buf[:len(codes)] = codes
+        buf[:len(codes)] = self.to_nibbles(codes) if self.nibbles else codes
         if counts is not None:
             cbuf[:len(codes)] = counts
         self.submit(len(codes), counts is not None)

@@ -196,8 +196,17 @@ int dst_run_rect_host(dst_ctx *ctx, int measure, int row_slot, int col_slot, uin
  * unchanged while the stream is open.  One owner thread, like the context. */
 typedef struct dst_stream dst_stream;
 int dst_stream_open(dst_ctx *ctx, int measure, int out_kind, size_t max_records, int depth, dst_stream **stream);
-/* The page-locked input buffer of the next batch: rows *pitch bytes apart (>= width, a multiple of 128), room
- * for max_records; encode straight into it.  *base_counts (may be NULL): max_records x 4 {A,T,G,C} for tn93
+/* The same with a choice of what crosses the host link (which bounds a streamed job: 64 records of 5 Mbp are 320 MB):
+ *  DST_WIRE_CODES    Paradis bytes, one per site (dst_stream_open);
+ *  DST_WIRE_NIBBLES  the HIGH NIBBLE of each code — all that any measure reads — two sites per byte, site 2k in the low
+ *                    four bits of byte k, site 2k + 1 in the high four; a row's unused trailing nibble is ignored.  The
+ *                    host writes encoding_array()[c] >> 4 (src/encoding.rs:4-41) instead of the code; 0 is not a code
+ *                    (DST_ERR_INVALID_CODE at collect).  Half the bytes, same results; base counts by code
+ *                    (use_base_counts == 0) are counted from the nibbles on the device like from the codes. */
+typedef enum { DST_WIRE_CODES = 0, DST_WIRE_NIBBLES = 1 } dst_wire;
+int dst_stream_open_wire(dst_ctx *ctx, int measure, int out_kind, size_t max_records, int depth, int wire, dst_stream **stream);
+/* The page-locked input buffer of the next batch: rows *pitch bytes apart (>= width — half of it, rounded up, for
+ * DST_WIRE_NIBBLES — and a multiple of 128), room for max_records; encode straight into it.  *base_counts (may be NULL): max_records x 4 {A,T,G,C} for tn93
  * (encode_count_bases(), src/fastaio.rs:120-145).  DST_ERR_STATE when every slot is in flight. */
 int dst_stream_acquire(dst_stream *stream, uint8_t **codes, size_t *pitch, uint32_t **base_counts);
 /* Queue the acquired buffer holding n_records records: H2D, pack, compare, D2H.  Returns without waiting.
@@ -288,6 +297,11 @@ size_t dst_out_bytes(int measure, int out_kind, uint64_t n_pairs);
  * upload on this context, from HIP events recorded on the launch stream (bench.py's roofline leg);
  * *finalize_ms is always 0: finalisation is fused into the pair kernel's epilogue */
 int dst_last_kernel_ms(dst_ctx *ctx, float *pair_ms, float *finalize_ms, float *pack_ms);
+
+/* The same over many launches without waiting for the device after each: means over the pair-kernel and pack-kernel
+ * launches of this context since the last call with reset != 0 (at most the 64 most recent of each; waits for the last
+ * one).  bench.py times its steps with one call at the end of the timed region. */
+int dst_kernel_ms_mean(dst_ctx *ctx, int reset, float *pair_ms, int *pair_launches, float *pack_ms, int *pack_launches);
 
 /* Diagnostic: the tile schedule one pair-kernel launch would use for rows [row_begin,row_end)
  * against n_cols records — (i0, j0) per workgroup in launch order, idle fillers as i0 = 2^32-1.

@@ -112,3 +112,48 @@ def test_errors_surface_at_collect_and_misuse_is_refused(eng):
     with pytest.raises(da.DistanceError):
         fresh.stream("raw", max_records=4)             # slot 0 not loaded
     fresh.close()
+
+
+@pytest.mark.parametrize("L", [777, 1000, 128, 1])
+def test_nibble_wire_format_gives_the_same_results(eng, L):
+    """DST_WIRE_NIBBLES: the codes' high nibbles, two sites per byte (half the bytes over the host link) — every measure,
+    odd and even widths, tallies and device-counted base counts — against the oracle, like the byte format."""
+    loaded = random_alignment(70, L, 5)
+    streamed = random_alignment(37, L, 6)
+    eng.upload(0, loaded)
+    for m in ALL:
+        want = oracle.all_pairs_rect(m, loaded, streamed).T            # [streamed][loaded]
+        got = []
+        with eng.stream(m, max_records=16, depth=3, nibbles=True) as st:
+            for b0 in range(0, len(streamed), 16):
+                if st.in_flight() == 2:
+                    got.append(st.pop())
+                st.push(streamed[b0:b0 + 16])
+            while st.in_flight():
+                got.append(st.pop())
+        got = np.concatenate(got)
+        if m in da.INT_MEASURES:
+            assert np.array_equal(got, want.astype(np.int64)), (m, L)
+        else:
+            assert np.isclose(got, want, rtol=0, atol=1e-12, equal_nan=True).all(), (m, L)
+    with eng.stream("tn93", max_records=37, depth=2, tallies=True, nibbles=True) as st:
+        st.push(streamed)
+        tl = st.pop()
+    for s in (0, 11, 36):
+        for i in (0, 69):
+            assert list(tl[s, i]) == [int(x) for x in oracle.tallies("tn93", loaded[i], streamed[s])]
+
+
+def test_nibble_zero_is_not_a_code(eng):
+    loaded = random_alignment(20, 300, 7)
+    batch = random_alignment(4, 300, 8)
+    eng.upload(0, loaded)
+    with eng.stream("raw", max_records=4, depth=2, nibbles=True) as st:
+        buf, _ = st.buffer()
+        nib = da.engine.Stream.to_nibbles(batch)
+        nib[2, 100] &= 0x0F                                  # site 201 of record 2: nibble 0
+        buf[:4] = nib
+        st.submit(4)
+        with pytest.raises(da.DistanceError) as e:
+            st.pop()
+        assert e.value.status == 3 and "record 2 at site 201" in e.value.message

@@ -5,7 +5,11 @@ number of batches synthesised in page-locked host memory by SURVEY 8(d)'s genera
 Two figures:
   value / device_resident   batches already in HBM: pack + compare per batch (inputs resident when timing starts)
   h2d_inclusive             the same batches from page-locked host memory through the overlapped pipeline
-                            (dst_stream_*: H2D of batch k+1 and D2H of batch k-1 under the compare of batch k)
+                            (dst_stream_*: H2D of batch k+1 and D2H of batch k-1 under the compare of batch k), for both
+                            wire formats (Paradis bytes; the codes' high nibbles, two sites per byte), with the ring
+                            slots filled in place — what a parser that encodes straight into the slot leaves behind —
+                            and, apart, with a host memcpy of every batch into its slot (the r02 figure: the copy, one
+                            thread, was what bounded it, not the link)
 N>1: the loaded set is replicated, batches are dealt round-robin to the ranks, no data-path collective
 (results stay with the rank that computed them, as each GPU would write its own part of the TSV): weak scaling.
 """
@@ -72,27 +76,36 @@ def bench_c4(args, rank, world, dev, dev_index):
     used = eng.last_path()
 
     # ---- H2D-inclusive: the overlapped pipeline from page-locked memory ----------------------------
-    def step_stream(st):
-        popped = 0
+    def step_stream(st, data, copy):
         for k in range(len(mine)):
             if st.in_flight() == st.depth - 1:
                 st.pop(copy=False)
-                popped += 1
             buf, _ = st.buffer()
-            buf[:B] = host[k].numpy()          # the caller's encode-into-the-buffer step (here: a memcpy)
+            if copy:
+                buf[:B] = data[k]              # stand-in for "the caller encodes into the buffer": one thread's memcpy
             st.submit(B)
         while st.in_flight():
             st.pop(copy=False)
 
-    with eng.stream(measure, max_records=B, depth=3) as st:
-        for _ in range(args.warmup):
-            step_stream(st)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_stream(st)
-        fence()
-        el_h2d = time.perf_counter() - t0
+    h2d = {}
+    host_nib = None
+    for wire in ("codes", "nibbles"):
+        if wire == "nibbles":
+            host_nib = [da.engine.Stream.to_nibbles(host[k].numpy()) for k in range(len(mine))]
+        data = [host[k].numpy() for k in range(len(mine))] if wire == "codes" else host_nib
+        for copy in (False, True):
+            with eng.stream(measure, max_records=B, depth=3, nibbles=(wire == "nibbles")) as st:
+                # every ring slot holds a real batch before timing starts (the in-place figures re-send what is there)
+                for _ in range(max(args.warmup, 1)):
+                    step_stream(st, data, True)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_stream(st, data, copy)
+                fence()
+                el = time.perf_counter() - t0
+            h2d[(wire, copy)] = el
+    el_h2d = h2d[("codes", False)]
 
     def maxed(x):
         if world == 1:
@@ -102,6 +115,7 @@ def bench_c4(args, rank, world, dev, dev_index):
         return float(t.item())
 
     el_res, el_h2d = maxed(el_res), maxed(el_h2d)
+    h2d = {k: maxed(v) for k, v in h2d.items()}
     if rank == 0:
         ms = 1e3 * el_res / args.steps
         kernel_ms = float(np.mean(k_ms))
@@ -128,11 +142,16 @@ def bench_c4(args, rank, world, dev, dev_index):
                        "generator": f"tools/synth (SURVEY 8(d)): xoshiro256**, seed {args.seed:#x} ^ 4"},
             "device_resident": {"pairs_per_s": pairs_per_step / (el_res / args.steps), "ms_per_step": ms,
                                 "note": "batches in HBM when timing starts: pack + split-L pair kernel per batch"},
-            "h2d_inclusive": {"pairs_per_s": pairs_per_step / (el_h2d / args.steps), "ms_per_step": 1e3 * el_h2d / args.steps,
-                              "host_GBps": nb * B * L / (el_h2d / args.steps) / 1e9,
-                              "note": "page-locked host batches through dst_stream_* (depth 3): memcpy into the ring slot, "
-                                      "H2D, pack, compare, D2H overlapped; the figure is bounded by the host link and the "
-                                      "host memcpy, never reported as `value`"},
+            "h2d_inclusive": {
+                **{f"{wire}{'_with_host_copy' if copy else ''}": {
+                    "pairs_per_s": pairs_per_step / (h2d[(wire, copy)] / args.steps),
+                    "ms_per_step": 1e3 * h2d[(wire, copy)] / args.steps,
+                    "link_GBps": nb * B * (L if wire == "codes" else (L + 1) // 2) / (h2d[(wire, copy)] / args.steps) / 1e9}
+                   for wire in ("codes", "nibbles") for copy in (False, True)},
+                "note": "page-locked host batches through dst_stream_* (depth 3): H2D, pack, compare, D2H overlapped; never "
+                        "reported as `value`.  codes: Paradis bytes; nibbles: DST_WIRE_NIBBLES (half the bytes).  "
+                        "*_with_host_copy adds a one-thread memcpy of every batch into its ring slot, the stand-in for a parser "
+                        "that does not write into the slot directly"},
             "roofline": {"bound": "valu", "achieved": lane_ops / 1e12, "peak": 256 * 4 * 32 * 2.4e9 / 1e12,
                          "unit": "Tlane-op/s", "frac": lane_ops / (256 * 4 * 32 * 2.4e9), "kernel": "pair_kernel (split-L)",
                          "kernel_ms": kernel_ms, "traffic": None,

@@ -49,8 +49,11 @@ for m in args.measures.split(","):
             if rep:
                 step.append(dt * 1e3)
                 kern.append(eng.last_kernel_ms()["pair_ms"])
-        chk = float(torch.nan_to_num(out.view(torch.float64) if m not in da.INT_MEASURES else out.view(torch.int64).double()).sum())
-        bits = int(out.view(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF     # exact, order-free: any changed bit shows
+        chk, bits = 0.0, 0          # in pieces: 200,000 records have 160 GB of results, no room for a converted copy
+        for lo in range(0, pairs, 1 << 28):
+            piece = out[lo:lo + (1 << 28)]
+            chk += float(torch.nan_to_num(piece.view(torch.float64) if m not in da.INT_MEASURES else piece.view(torch.int64).double()).sum())
+            bits = (bits + int(piece.view(torch.int64).sum().item())) & 0xFFFFFFFFFFFFFFFF     # exact, order-free: any changed bit shows
         print(f"{m:7s} {path:10s} used={eng.last_path():10s} step {np.median(step):9.3f} ms  pair kernel {np.median(kern):9.3f} ms"
               f"  {pairs / np.median(step) * 1e3:.3e} pairs/s  checksum {chk:.6f} bits {bits:016x}")
 eng.close()
