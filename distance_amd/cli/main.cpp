@@ -1212,8 +1212,13 @@ int main(int argc, char **argv)
         bool all_dispatched = false;
         const size_t window = (size_t)G * (kDepth + 2);     // bound on batches between dispatch and write
         std::vector<dst_stream *> streams((size_t)G, nullptr);
+        // what crosses the host link: the codes' high nibbles, two sites per byte (all a measure reads: half the bytes);
+        // DISTANCE_WIRE=codes keeps the Paradis bytes (tests run both)
+        const char *wire_env = std::getenv("DISTANCE_WIRE");
+        const bool nibbles = !(wire_env && std::strcmp(wire_env, "codes") == 0);
         for (int g = 0; g < G; ++g)
-            gpus[g].check(dst_stream_open(gpus[g].h, measure, DST_OUT_TALLY, batch_records, kDepth, &streams[g]), "stream open");
+            gpus[g].check(dst_stream_open_wire(gpus[g].h, measure, DST_OUT_TALLY, batch_records, kDepth,
+                                               nibbles ? DST_WIRE_NIBBLES : DST_WIRE_CODES, &streams[g]), "stream open");
         auto gpu_stream_worker = [&](int g) {
             std::deque<Item> inflight;
             auto collect_one = [&]() {
@@ -1262,8 +1267,19 @@ int main(int argc, char **argv)
                 uint32_t *cbuf = nullptr;
                 gpus[g].check(dst_stream_acquire(streams[g], &buf, &pitch, &cbuf), "stream acquire");
                 const Alignment &al = *it.batch;
-                for (size_t r = 0; r < al.n; ++r)
-                    std::memcpy(buf + r * pitch, al.codes.data() + r * al.width, al.width);
+                for (size_t r = 0; r < al.n; ++r) {
+                    const uint8_t *src = al.codes.data() + r * al.width;
+                    uint8_t *dst = buf + r * pitch;
+                    if (!nibbles) {
+                        std::memcpy(dst, src, al.width);
+                        continue;
+                    }
+                    const size_t half = al.width / 2;
+                    for (size_t k = 0; k < half; ++k)   // site 2k in the low nibble, 2k + 1 in the high one
+                        dst[k] = (uint8_t)((src[2 * k] >> 4) | (src[2 * k + 1] & 0xF0u));
+                    if (al.width & 1)
+                        dst[half] = (uint8_t)((src[al.width - 1] >> 4) | 0xF0u);
+                }
                 if (measure == DST_TN93)
                     std::memcpy(cbuf, al.counts.data(), al.n * 4 * sizeof(uint32_t));
                 gpus[g].check(dst_stream_submit(streams[g], al.n, measure == DST_TN93 ? 1 : 0), "stream submit");

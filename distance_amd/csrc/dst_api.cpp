@@ -610,7 +610,7 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
 
 // Which path is cheapest for this launch?  The sampled reference gives, per site, the fraction p_s of records that
 // deviate from it: a pair costs the dense path L sites whatever the data; the consensus path one output plus about
-// sum_s p_s^2 intersection events; the hybrid path the dense cost of the H hot sites (p_s > 3.3 %), one round trip of
+// sum_s p_s^2 intersection events; the hybrid path the dense cost of the H hot sites (p_s > 5 %: kHotPermille), one round trip of
 // their tallies through HBM, and the events of the cold sites only.  Constants: measured on MI355X, seconds
 // (tools/calibrate.py, profiles/r02/consensus_calibration.txt).
 // share: this launch's part of the pair space of the two sets.  A run over a row range is one slab of a job that goes

@@ -115,7 +115,7 @@ int dst_set_prep_threshold(dst_ctx *ctx, double site_comparisons);
  *                      Shapes its lists cannot index (zero-width alignments, 2^28 or more records or sites,
  *                      more than 2^31 differences in a set) run dense even when this is selected.
  *  DST_PATH_HYBRID:    consensus path for the "cold" columns, dense kernels for the hot ones (columns where more than
- *                      3.3 % of a sample of the records deviate from the plurality: clade-defining mutations), whose
+ *                      5 % of a sample of the records deviate from the plurality: clade-defining mutations), whose
  *                      tallies the consensus kernel adds in.  Alignments with phylogenetic structure stay fast.
  *                      Without hot columns it is the consensus path; with mostly hot columns the dense one.
  *  DST_PATH_AUTO:      (default) per launch, whichever a sampled estimate of the alignment's diversity

@@ -51,6 +51,10 @@ def cli(args, stdin=None):
     h = subprocess.run([CLI] + args, input=stdin, capture_output=True, env=dict(os.environ, DISTANCE_HOST_FORMAT="1"))
     assert h.returncode == 0, h.stderr.decode()
     assert r.stdout == h.stdout, "GPU-formatted and host-formatted TSV differ"
+    if "-s" in args:   # stream mode sends the codes' high nibbles by default (DST_WIRE_NIBBLES): the byte format must agree
+        w = subprocess.run([CLI] + args, input=stdin, capture_output=True, env=dict(os.environ, DISTANCE_WIRE="codes"))
+        assert w.returncode == 0, w.stderr.decode()
+        assert r.stdout == w.stdout, "4-bit and 8-bit wire formats give different TSV"
     return r.stdout.decode()
 
 

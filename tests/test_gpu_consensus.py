@@ -387,6 +387,11 @@ def test_every_wave_shape_of_the_fill_pass(eng, n):
     want = {(m, r): ref.run_square(m, r, r + 1) for m in ("n_high", "raw", "tn93") for r in rows}
     want_t = {r: ref.run_square("tn93", r, r + 1, tallies=True) for r in rows}
     ref.close()
+    # ... and the reference tallies themselves against the oracle, directly (not only through the dense path)
+    for r in rows[:3]:
+        for j in sorted({r + 1, n // 2, n - 1} - set(range(r + 1))):
+            assert list(want_t[r][j - r - 1]) == [int(x) for x in oracle.tallies("tn93", codes[r], codes[j])], (r, j)
+            assert int(want[("n_high", r)][j - r - 1]) == oracle.pair_distance("n_high", codes[r], codes[j])
     for threshold in (0.0, 1e30):                      # fused preparation / lists built at the first run
         eng.set_prep_threshold(threshold)
         for path in ("consensus", "hybrid"):
@@ -416,6 +421,11 @@ def test_event_heavy_launches_on_every_path(eng, L):
     want = {(m, r): ref.run_square(m, r, r + 2 if r + 2 < n else r + 1) for m in ALL for r in rows}
     want_t = {m: ref.run_square(m, 3, 6, tallies=True) for m in ("raw", "k80", "tn93")}
     ref.close()
+    # the no-roles variant (EW == 8) against the oracle directly: rows 3..5 of the tallies, a handful of columns
+    for m in ("raw", "k80", "tn93"):
+        for j in (4, 7, n // 2, n - 1):
+            at = j - 4                                   # pair (3, j) is entry j - 4 of row 3's slab
+            assert list(want_t[m][at]) == [int(x) for x in oracle.tallies(m, codes[3], codes[j])], (m, j)
     for path in ("consensus", "hybrid"):
         eng.set_path("auto")
         eng.upload(0, codes)
@@ -423,5 +433,13 @@ def test_event_heavy_launches_on_every_path(eng, L):
         for (m, r), w in want.items():
             assert np.array_equal(eng.run_square(m, r, r + 2 if r + 2 < n else r + 1), w, equal_nan=True), (path, m, r)
         for m, w in want_t.items():
-            assert np.array_equal(eng.run_square(m, 3, 6, tallies=True), w), (path, m)
+            got = eng.run_square(m, 3, 6, tallies=True)
+            assert np.array_equal(got, w), (path, m)
+            for j in (4, n // 2, n - 1):                 # and this path's own tallies against the oracle
+                assert list(got[j - 4]) == [int(x) for x in oracle.tallies(m, codes[3], codes[j])], (path, m, j)
+        for m in ("jc69", "tn93"):                       # device distances of the variant: BASELINE's 1e-12
+            d = eng.run_square(m, 3, 4)
+            for j in (4, n // 2, n - 1):
+                w = oracle.pair_distance(m, codes[3], codes[j])
+                assert (np.isnan(w) and np.isnan(d[j - 4])) or d[j - 4] == w or abs(d[j - 4] - w) <= 1e-12, (path, m, j)
     eng.set_path("auto")
