@@ -69,7 +69,8 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 void free_set(DeviceSet &s)
 {
     void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.range_start, s.rec.pre_cold, s.rec.pre_slots,
-                    s.site.inl, s.site.ent, s.aconst};
+                    s.site.inl, s.site.ent, s.aconst, s.runs.index, s.runs.mask, s.runs.known, s.runs.panel_first, s.runs.state,
+                    s.runs.aent, s.runs.corr, s.runs.corr_t};   // (runs.cnt_run / run_cold / run_hot / ids live in the pre_cold and index blocks)
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -114,6 +115,9 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
     s.ref.valid = s.rec.valid = s.site.valid = s.rec.pre_valid = s.rec.ranges_valid = false;
     s.aconst_family = -1;
+    s.runs.active = false;
+    s.runs.n_run = 0;
+    s.runs.corr_family = -1;
     return DST_OK;
 }
 
@@ -156,15 +160,26 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
     if (want_lists) {
         rc = alloc_ref(ctx, s);
         if (!rc && s.rec.pre_cap < n + 1) {
-            // one block: [n + 1] cold counts, [n + 1] hot counts, the two totals — one allocation, one memset per upload
+            // one block: [n + 1] cold counts, [n + 1] hot counts, the two totals, then the run-chunk counters (RunIndex):
+            // [n + 1] run chunks, [n + 1] their cold entries, [n + 1] their hot entries — one allocation, cleared per upload
             if (s.rec.pre_cold)
                 HIP_TRY(ctx, hipFree(s.rec.pre_cold));
             s.rec.pre_cold = s.rec.pre_hot = nullptr;
             s.rec.pre_totals = nullptr;
             s.rec.pre_cap = 0;
-            const size_t words = 2 * (n + 1) + 4 + ((2 * (n + 1)) & 1);   // totals on an 8-byte boundary
+            const size_t words = 5 * (n + 1) + 4 + ((2 * (n + 1)) & 1);   // totals on an 8-byte boundary
             HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, words * sizeof(uint32_t)));
             s.rec.pre_cap = n + 1;
+        }
+        if (!rc && s.runs.n_alloc < n + 1) {   // the run records' numbers and ids, and what the report kernel decides
+            if (s.runs.index)
+                HIP_TRY(ctx, hipFree(s.runs.index));
+            s.runs.index = s.runs.ids = nullptr;
+            s.runs.n_alloc = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&s.runs.index, 2 * (n + 1) * sizeof(uint32_t)));
+            s.runs.n_alloc = n + 1;
+            if (!s.runs.state)
+                HIP_TRY(ctx, hipMalloc((void **)&s.runs.state, 4 * sizeof(uint32_t)));
         }
         if (!rc)
             rc = ensure_bytes(ctx, (void **)&s.rec.pre_slots, &s.rec.pre_slots_cap, s.nchunks * s.npad * sizeof(uint4));
@@ -174,8 +189,12 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
             const size_t cap = s.rec.pre_cap, pad = (2 * cap) & 1;
             s.rec.pre_hot = s.rec.pre_cold + cap;
             s.rec.pre_totals = reinterpret_cast<unsigned long long *>(s.rec.pre_cold + 2 * cap + pad);
+            s.runs.cnt_run = s.rec.pre_cold + 2 * cap + pad + 4;
+            s.runs.run_cold = s.runs.cnt_run + cap;
+            s.runs.run_hot = s.runs.run_cold + cap;
+            s.runs.ids = s.runs.index + s.runs.n_alloc;
             // (the pack's counts and first-invalid-byte cell are cleared on the sample's way: no fills of their own)
-            HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 2 * cap + pad + 4, d_first_bad));
+            HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 5 * cap + pad + 4, d_first_bad));
             HIP_TRY(ctx, launch_hot_list(s, stream));
         }
         pl.ref_planes = s.ref.planes;
@@ -185,6 +204,12 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         pl.cnt_cold = s.rec.pre_cold;
         pl.cnt_hot = s.rec.pre_hot;
         pl.slots = s.rec.pre_slots;
+        static const bool no_runs = std::getenv("DST_NO_RUN_RECORDS") != nullptr;   // measurement knob: r02's lists
+        if (!no_runs) {
+            pl.cnt_run = s.runs.cnt_run;
+            pl.run_cold = s.runs.run_cold;
+            pl.run_hot = s.runs.run_hot;
+        }
     }
     if (!want_lists)
         HIP_TRY(ctx, hipMemsetAsync(d_first_bad, 0xFF, sizeof(unsigned long long), stream));
@@ -228,9 +253,12 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     if (rc)
         return rc;
     // the device writes its report (first invalid byte, statistics, totals) into page-locked host memory: one wait
+    // run records (RunIndex): at most a third of the records, and correction tables (two, up to four words each) below 6 GB
+    const uint32_t max_run = (uint32_t)std::min<uint64_t>(n / 3, 6000000000ull / (32ull * std::max<size_t>(n, 1)));
     HIP_TRY(ctx, launch_report(ctx->d_first_bad,
                                want_lists ? reinterpret_cast<const unsigned long long *>(s.ref.stats) : nullptr,
-                               want_lists ? s.rec.pre_cold : nullptr, want_lists ? s.rec.pre_hot : nullptr, n, ctx->d_report, stream));
+                               want_lists ? s.rec.pre_cold : nullptr, want_lists ? s.rec.pre_hot : nullptr, n, ctx->d_report, stream,
+                               want_lists ? &s.runs : nullptr, max_run));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     const unsigned long long first_bad = ctx->h_report[0], totals[2] = {ctx->h_report[9], ctx->h_report[10]};
     if (want_lists)
@@ -247,6 +275,10 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
         s.rec.pre_epoch = s.epoch;
         s.rec.pre_total_cold = totals[0];
         s.rec.pre_total_hot = totals[1];
+        s.runs.n_run = s.rec.pre_valid ? (uint32_t)ctx->h_report[11] : 0u;
+        s.runs.removed = s.runs.n_run ? ctx->h_report[12] : 0;
+        s.runs.active = s.runs.n_run != 0;
+        s.runs.corr_family = -1;
     }
     return DST_OK;
 }
@@ -529,6 +561,8 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     unsigned long long total = 0;
     const uint32_t *scan_src0 = nullptr, *scan_src1 = nullptr;
     const bool from_pack = &s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch;
+    if (!from_pack)
+        s.runs.active = false;   // lists from the planes keep every entry (index_kernel knows no run chunks)
     if (from_pack) {
         // the pack counted the list lengths against this very reference: no pass over the planes, no round trip
         // (the scan below reads the counts where the pack left them)
@@ -568,6 +602,22 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
                                   want_sites ? s.rec.range_start : nullptr));
     if (want_sites)
         HIP_TRY(ctx, launch_site_buckets(s, n_panels, d_ovf_n, stream));
+    if (from_pack && s.runs.active) {
+        // run records: their run chunks as bit masks (from the slots' flags) and the known reference sites per chunk, for
+        // these lists' flavour (the hybrid path's lists leave the hot sites to the dense kernels)
+        RunIndex &ru = s.runs;
+        ru.mask_words = (s.nchunks + 31) / 32;
+        rc = ensure_bytes(ctx, (void **)&ru.mask, &ru.mask_cap, (size_t)ru.n_run * ru.mask_words * sizeof(uint32_t));
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&ru.known, &ru.known_cap, ((s.nchunks + 31) / 32 * 32) * sizeof(uint32_t));
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&ru.panel_first, &ru.panel_cap, ((size_t)n_panels + 2) * sizeof(uint32_t));
+        if (rc)
+            return rc;
+        HIP_TRY(ctx, launch_run_masks(s, stream));
+        HIP_TRY(ctx, launch_run_known(s, refset.ref.planes, hot_planes, stream));
+        ru.corr_family = -1;
+    }
     // runs queued on other streams wait for this on the device
     rc = publish_prep(ctx, stream);
     if (rc)
@@ -596,7 +646,21 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
         rc = ensure_bytes(ctx, (void **)&s.aconst, &s.aconst_cap, s.npad * kMaxWords * sizeof(uint32_t));
     if (rc)
         return rc;
+    if (s.runs.active) {
+        // the entries' a-words (what corr_kernel sums) and the two correction tables of this (family, packing)
+        RunIndex &ru = s.runs;
+        const size_t words = (size_t)family_words(family, wide);
+        rc = ensure_bytes(ctx, (void **)&ru.aent, &ru.aent_cap, (size_t)kMaxWords * std::max<size_t>(s.rec.total, 1) * sizeof(uint32_t));
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&ru.corr, &ru.corr_cap, words * ru.n_run * s.n * sizeof(uint32_t));
+        if (!rc)
+            rc = ensure_bytes(ctx, (void **)&ru.corr_t, &ru.corr_t_cap, words * ru.n_run * s.n * sizeof(uint32_t));
+        if (rc)
+            return rc;
+    }
     HIP_TRY(ctx, launch_aconst(s, family, wide, ctx->d_lut, stream));
+    if (s.runs.active)
+        HIP_TRY(ctx, launch_run_tables(s, family, wide, s.rec.without_hot, ctx->d_lut, stream));
     rc = publish_prep(ctx, stream);
     if (rc)
         return rc;
@@ -617,6 +681,17 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
 // on to cover the other rows (the CLI's slabs, a rank's sub-slabs): the lists are built once and serve all of them, so
 // a slab is charged its share of the build — every slab then decides like the whole job would (charged in full, each
 // 4 Mi-pair slab of a 50,000-record run chose the dense kernels: 0.9 ms instead of 0.03).
+// Run records (RunIndex) leave their run chunks out of the lists: the sample's statistics, taken before that, over-state
+// what the pair kernel will meet.  List lengths shrink by f = kept / (kept + removed) entries, events (both records
+// deviate at a site) by about f^2.
+double run_scale(const DeviceSet &cols)
+{
+    if (!cols.runs.active)
+        return 1.0;
+    const double kept = (double)(cols.rec.pre_total_cold + cols.rec.pre_total_hot);
+    return kept / std::max(kept + (double)cols.runs.removed, 1.0);
+}
+
 int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uint64_t pairs, uint32_t ntiles, double share)
 {
     //                                            n       n_high  raw      jc69     k80      tn93
@@ -628,8 +703,9 @@ int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uin
     const double S = (double)std::max<uint64_t>(st[3], 1);
     const double n_hot = (double)st[4];
     // the sample's sum of squared deviant counts over-states sum p^2 by about (mean list length) / S
-    const double mean_list = (double)st[1] / S, mean_list_cold = (double)st[6] / S;  // differences per record
-    const double events = (double)st[2] / (S * S), events_cold = (double)st[7] / (S * S);
+    const double f = run_scale(cols);
+    const double mean_list = f * (double)st[1] / S, mean_list_cold = f * (double)st[6] / S;  // differences per record
+    const double events = f * f * (double)st[2] / (S * S), events_cold = f * f * (double)st[7] / (S * S);
     const double dense = (double)pairs * (double)cols.len / dense_site_pairs_per_s[measure];
     // building the lists reads four bit-planes twice; walking a row's list costs one bucket lookup per panel
     const bool have_lists = rows.rec.valid && cols.site.valid;
@@ -638,8 +714,13 @@ int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uin
     const double build = ((double)(rows.n + cols.n) * (double)cols.len * (from_pack ? 0.1e-12 : 0.5e-12) + 1.5e-4) *
                          std::min(1.0, std::max(share, 1e-3));
     const double walk = (double)ntiles * kConsensusRowsPerTile * 1e-9 / 256.0;
+    // run records: their correction tables (one test per list entry and run record, ~5e-14 s) and what the pair kernel
+    // adds from them (two words per pair with a run record)
+    const double run_tables = cols.runs.active ? ((double)cols.n * cols.runs.n_run * (mean_list * 5e-14 + 2e-12)) * std::min(1.0, std::max(share, 1e-3))
+                                                     + (double)pairs * 2.0 * cols.runs.n_run / std::max<double>((double)cols.n, 1.0) * 1.0e-12
+                                               : 0.0;
     const double cons = (double)pairs * (out_s_per_pair[measure] + events * event_s) +
-                        ((have_lists && !rows.rec.without_hot) ? 0.0 : build) + walk * mean_list + 3e-5;
+                        ((have_lists && !rows.rec.without_hot) ? 0.0 : build) + walk * mean_list + 3e-5 + run_tables;
     double best = std::min(dense, cons);
     int path = cons < dense ? DST_PATH_CONSENSUS : DST_PATH_DENSE;
     if (n_hot > 0 && n_hot * 4 < (double)cols.len) {
@@ -739,6 +820,13 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             path = n_hot == 0 ? DST_PATH_CONSENSUS : DST_PATH_DENSE;  // nothing hot / mostly hot: the plain paths
         if (path != DST_PATH_DENSE) {
             const bool without_hot = path == DST_PATH_HYBRID;
+            if (!square && cols.runs.active) {
+                // a column set whose run records' lists are stripped serves the square job only (the corrections are
+                // between its own records): two files / stream batches rebuild its lists from the planes, whole
+                cols.runs.active = false;
+                cols.rec.valid = cols.site.valid = cols.rec.pre_valid = false;
+                cols.aconst_family = -1;
+            }
             rc = ensure_index(ctx, cols, cols, true, without_hot, stream);
             if (!rc && &rows != &cols)
                 rc = ensure_index(ctx, rows, cols, false, without_hot, stream);
@@ -836,7 +924,8 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
         {   // the sample's view of this launch's event load (the same figures the path choice reads)
             const uint64_t *st = cols.ref.h_stats;
             const double S = (double)std::max<uint64_t>(st[3], 1);
-            const double events = (double)(hybrid ? st[7] : st[2]) / (S * S), list = (double)(hybrid ? st[6] : st[1]) / S;
+            const double f = run_scale(cols);
+            const double events = f * f * (double)(hybrid ? st[7] : st[2]) / (S * S), list = f * (double)(hybrid ? st[6] : st[1]) / S;
             cl.heavy_events = events > 1.0 ? 2 : events > 0.5 || list > 100.0 ? 1 : 0;
         }
         ctx->last_path = path;
@@ -1127,6 +1216,18 @@ int dst_set_path(dst_ctx *ctx, int path)
 }
 
 int dst_last_path(const dst_ctx *ctx) { return ctx ? ctx->last_path : -1; }
+
+int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_t *entries_removed)
+{
+    if (!ctx || slot < 0 || slot > 1)
+        return DST_ERR_ARG;
+    const DeviceSet &s = ctx->set[slot];
+    if (run_records)
+        *run_records = s.runs.active ? s.runs.n_run : 0;
+    if (entries_removed)
+        *entries_removed = s.runs.active ? s.runs.removed : 0;
+    return DST_OK;
+}
 
 int dst_set_variant(dst_ctx *ctx, int variant)
 {

@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
                                                         const uint4 *__restrict__ hot_planes, uint32_t n,
                                                         uint32_t nchunks, uint32_t npad,
                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_ent,
-                                                        uint32_t *__restrict__ range_start, uint32_t rec_first, uint32_t ent_cap)
+                                                        uint32_t *__restrict__ range_start, uint32_t rec_first, uint32_t ent_cap,
+                                                        const uint32_t *__restrict__ run_index, const uint32_t *__restrict__ run_state)
 {
     // records [rec_first, n) (rec_off[0] is record rec_first's offset); entries at or beyond ent_cap are not written:
     // one rank's share of a set, whose lists go into an exchange block of fixed size (dst_upload_shared)
@@ -508,6 +509,8 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
     const size_t ps = (size_t)nchunks * npad;
     uint32_t run = 0;
     const uint32_t base0 = live ? rec_off[r - rec_first] : 0u;
+    // a run record (RunIndex: kRunMin and more chunks of N) leaves its run chunks out of its list
+    const bool run_record = live && run_state && run_state[1] != 0 && run_index[r] != 0xFFFFFFFFu;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     // two steps ahead
     uint4 nslot = (live && cl < nchunks) ? slots[(size_t)cl * npad + r] : zero4;
@@ -519,8 +522,9 @@ __global__ __launch_bounds__(256) void slot_fill_kernel(const uint4 *__restrict_
         if (c0 + 2 * CLN < nchunks)
             nslot2 = (live && c + 2 * CLN < nchunks) ? slots[(size_t)(c + 2 * CLN) * npad + r] : zero4;
         const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w};
-        const uint32_t cnt_all = slot.x & 0xFFu;
-        const bool big = cnt_all > kSlotEntries;
+        const bool run_chunk = (slot.x >> 8) & 1u;                 // 128 sites of N: nothing inline in the slot
+        const uint32_t cnt_all = run_chunk && run_record ? 0u : slot.x & 0xFFu;
+        const bool big = cnt_all > kSlotEntries || (run_chunk && cnt_all != 0);
         // entries this lane emits: from the slot, or (big) from the planes
         uint32_t pc = 0;
         if (big) {
@@ -878,60 +882,148 @@ __global__ __launch_bounds__(256) void sum2_u32_kernel(const uint32_t *__restric
 
 // What the host wants to know after an upload, gathered into one page-locked host block by the device itself (three
 // blocking device-to-host copies of 8-64 bytes cost ~20 us each: a fifth of a 10,000-record step)
+// RunsArg: the run-chunk counters of the pack (RunIndex) and where the decision goes; cnt_run == NULL: not looked for
+struct RunsArg {
+    uint32_t *cnt_run, *run_cold, *run_hot, *index, *ids, *state;
+    uint32_t max_run;   // more run records than this: stripping stays off (the correction tables would not pay / fit)
+};
+
 __global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *__restrict__ first_bad,
                                                       const unsigned long long *__restrict__ stats,
-                                                      const uint32_t *__restrict__ cnt0, const uint32_t *__restrict__ cnt1, uint32_t n,
-                                                      unsigned long long *report)
+                                                      uint32_t *__restrict__ cnt0, uint32_t *__restrict__ cnt1, uint32_t n,
+                                                      unsigned long long *report, RunsArg runs)
 {
     // the list totals: the pack's two count arrays summed here (a kernel of their own they were one more launch)
-    __shared__ unsigned long long part[16][2];
-    unsigned long long s0 = 0, s1 = 0;
+    __shared__ unsigned long long part[16][4];
+    __shared__ uint32_t wave_tot[16], base_s, strip_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    auto block_sums = [&](unsigned long long (&v)[4]) {   // v[k] summed over the block, in every thread
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                v[k] += __shfl_xor(v[k], o);
+            if (lane == 0)
+                part[wv][k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = 0;
+            for (int w = 0; w < 16; ++w)
+                v[k] += part[w][k];
+        }
+        __syncthreads();
+    };
+    // pass 1: {cold entries, hot entries, run chunks, run records}
+    unsigned long long v[4] = {0, 0, 0, 0};
     if (cnt0)
-        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {   // 16 loads in flight per thread: one block, latency-bound
-            uint32_t a[8], b[8];
+        for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {   // many loads in flight per thread: one block, latency-bound
+            uint32_t a[8], b[8], r[8];
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
                 const uint32_t i = i0 + 1024 * u;
                 a[u] = i < n ? cnt0[i] : 0u;
                 b[u] = i < n ? cnt1[i] : 0u;
+                r[u] = (runs.cnt_run && i < n) ? runs.cnt_run[i] : 0u;
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
-                s0 += a[u];
-                s1 += b[u];
+                v[0] += a[u];
+                v[1] += b[u];
+                v[2] += r[u];
+                v[3] += r[u] >= kRunMin ? 1u : 0u;
             }
         }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o);
-        s1 += __shfl_xor(s1, o);
+    block_sums(v);
+    const bool any_run = v[2] != 0;
+    const bool strip = v[3] != 0 && v[3] <= runs.max_run;
+    if (any_run) {
+        // pass 2: the entries of run chunks go back into the list lengths of every record that keeps them; the run
+        // records get their numbers, in record order (1,024 records per round, a block scan of the flags)
+        if (tid == 0)
+            base_s = 0;
+        unsigned long long w2[4] = {0, 0, 0, 0};
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+            const uint32_t i = i0 + tid;
+            const bool is_run = i < n && strip && runs.cnt_run[i] >= kRunMin;
+            if (i < n) {
+                const uint32_t rc = runs.run_cold[i], rh = runs.run_hot[i];
+                if (!is_run) {
+                    if (rc)
+                        cnt0[i] += rc;
+                    if (rh)
+                        cnt1[i] += rh;
+                    w2[0] += rc;
+                    w2[1] += rh;
+                } else {
+                    w2[2] += rc + rh;
+                }
+            }
+            if (strip) {   // (uniform)
+                const unsigned long long m = __ballot(is_run);
+                if (lane == 0)
+                    wave_tot[wv] = (uint32_t)__builtin_popcountll(m);
+                __syncthreads();
+                uint32_t before = base_s, total = 0;
+                for (uint32_t w = 0; w < 16; ++w) {
+                    if (w < wv) before += wave_tot[w];
+                    total += wave_tot[w];
+                }
+                if (i < n) {
+                    const uint32_t h = before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    runs.index[i] = is_run ? h : 0xFFFFFFFFu;
+                    if (is_run)
+                        runs.ids[h] = i;
+                }
+                __syncthreads();
+                if (tid == 0)
+                    base_s += total;
+                __syncthreads();
+            }
+        }
+        block_sums(w2);
+        v[0] += w2[0];
+        v[1] += w2[1];
+        v[2] = w2[2];
+    } else {
+        v[2] = 0;
     }
-    if ((threadIdx.x & 63u) == 0) {
-        part[threadIdx.x >> 6][0] = s0;
-        part[threadIdx.x >> 6][1] = s1;
+    if (runs.state && tid == 0) {
+        runs.state[0] = strip ? (uint32_t)v[3] : 0u;
+        runs.state[1] = strip ? 1u : 0u;
     }
-    __syncthreads();
-    const uint32_t t = threadIdx.x;
-    if (t == 0)
+    (void)strip_s;
+    if (tid == 0)
         report[0] = *first_bad;
-    else if (t <= 8)
-        report[t] = stats ? stats[t - 1] : 0ull;
-    else if (t < (uint32_t)kReportWords) {
-        unsigned long long sum = 0;
-        for (int w = 0; w < 16; ++w)
-            sum += part[w][t - 9];
-        report[t] = sum;
-    }
+    else if (tid <= 8)
+        report[tid] = stats ? stats[tid - 1] : 0ull;
+    else if (tid == 9)
+        report[9] = v[0];
+    else if (tid == 10)
+        report[10] = v[1];
+    else if (tid == 11)
+        report[11] = strip ? v[3] : 0ull;   // run records (0: the lists keep every entry)
+    else if (tid == 12)
+        report[12] = strip ? v[2] : 0ull;   // entries their lists lost
 }
 
 // =============================================================================================
 // per-record constants A_k
 // =============================================================================================
+struct RunConst {   // aconst_kernel's view of the run records (all NULL: no stripping)
+    uint32_t *aent;              // [kMaxWords][aent_stride] a-words of every list entry, for corr_kernel
+    size_t aent_stride;
+    const uint32_t *index, *mask, *known;
+    uint32_t mask_words;
+};
+
 __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict__ off,
                                                      const uint32_t *__restrict__ ent,
                                                      const ConsensusLut *__restrict__ lut, int family, int wide,
                                                      int words, uint32_t n, uint32_t npad,
-                                                     uint32_t *__restrict__ aconst)
+                                                     uint32_t *__restrict__ aconst, RunConst rc)
 {
     const uint32_t lane = threadIdx.x & 63u, r = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (r >= n)
@@ -952,9 +1044,27 @@ __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict_
                 continue;
             const uint32_t *a = lut->a[family][wide][(e[u] >> kSiteBits) & 7u][e[u] >> kEntryShift];
 #pragma unroll
-            for (int w = 0; w < kMaxWords; ++w)
+            for (int w = 0; w < kMaxWords; ++w) {
                 acc[w] += a[w];
+                if (rc.aent && w < words)
+                    rc.aent[(size_t)w * rc.aent_stride + i + 64 * u] = a[w];
+            }
         }
+    }
+    // a run record's constant also takes back what the identity counts on its run chunks: F over them (RunIndex)
+    if (rc.index && rc.index[r] != 0xFFFFFFFFu) {
+        uint32_t known = 0;
+        for (uint32_t k = lane; k < rc.mask_words; k += 64) {
+            uint32_t m = rc.mask[(size_t)rc.index[r] * rc.mask_words + k];
+            while (m) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                known += rc.known[32u * k + bit];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < kMaxWords; ++w)
+            acc[w] -= known * lut->unit[family][wide][w];
     }
 #pragma unroll
     for (int w = 0; w < kMaxWords; ++w) {
@@ -963,6 +1073,142 @@ __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict_
             acc[w] += __shfl_xor(acc[w], o);
         if (lane == 0 && w < words)
             aconst[(size_t)w * npad + r] = acc[w];
+    }
+}
+
+// known reference sites of every 128-site chunk (the F of a run chunk); hot_planes given: cold sites only
+__global__ __launch_bounds__(256) void run_known_kernel(const uint4 *__restrict__ ref_planes, const uint4 *__restrict__ hot_planes,
+                                                        uint32_t nchunks, uint32_t *__restrict__ known)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks)
+        return;
+    const uint4 A = ref_planes[c], G = ref_planes[nchunks + c], C = ref_planes[2 * (size_t)nchunks + c], T = ref_planes[3 * (size_t)nchunks + c];
+    uint4 k;
+    k.x = (A.x ^ G.x ^ C.x ^ T.x) & ~((A.x & G.x) | (C.x & T.x));
+    k.y = (A.y ^ G.y ^ C.y ^ T.y) & ~((A.y & G.y) | (C.y & T.y));
+    k.z = (A.z ^ G.z ^ C.z ^ T.z) & ~((A.z & G.z) | (C.z & T.z));
+    k.w = (A.w ^ G.w ^ C.w ^ T.w) & ~((A.w & G.w) | (C.w & T.w));
+    if (hot_planes) {
+        const uint4 h = hot_planes[c];
+        k.x &= ~h.x;
+        k.y &= ~h.y;
+        k.z &= ~h.z;
+        k.w &= ~h.w;
+    }
+    known[c] = popc4(k);
+}
+
+// the run chunks of every run record as a bit mask, from the flags the pack left in the slots
+__global__ __launch_bounds__(256) void run_masks_kernel(const uint4 *__restrict__ slots, const uint32_t *__restrict__ ids, uint32_t n_run,
+                                                        uint32_t nchunks, uint32_t npad, uint32_t mask_words, uint32_t *__restrict__ mask)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_run * mask_words)
+        return;
+    const uint32_t h = i / mask_words, k = i - h * mask_words, r = ids[h];
+    uint32_t m = 0;
+    for (uint32_t bit = 0; bit < 32; ++bit) {
+        const uint32_t c = 32u * k + bit;
+        if (c < nchunks && ((slots[(size_t)c * npad + r].x >> 8) & 1u))
+            m |= 1u << bit;
+    }
+    mask[i] = m;
+}
+
+// first run record of every column panel: panel_first[p] = run records with id < p * kPanelCols (ids ascending)
+__global__ __launch_bounds__(256) void run_panels_kernel(const uint32_t *__restrict__ ids, uint32_t n_run, uint32_t n_panels,
+                                                         uint32_t *__restrict__ panel_first)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p > n_panels)
+        return;
+    const uint32_t key = p * kPanelCols;
+    uint32_t lo = 0, hi = n_run;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (ids[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    panel_first[p] = lo;
+}
+
+// X's terms (RunIndex) for every (run record h, record r):
+//     C(h, r) = - A_r(M_h)  [r's list entries in h's run chunks]  +  F(M_h n M_r) if r is a run record with a higher id
+// so that a pair (q, t) gets C(t, q) when t is a run record and C(q, t) when q is one — both terms once, the F term once.
+// One block = 64 records x 64 run records: wave w takes 16 of the records, lane = run record; a record's entries are the
+// same for all lanes (broadcast loads), the run record's mask word is one gathered load per entry.  The tile leaves
+// through LDS in both orientations: corr[w][h][r] (what a run ROW adds to a panel) and corr_t[w][r][h] (what the run
+// COLUMNS of a panel add to a row).
+template <int W>
+__global__ __launch_bounds__(256) void corr_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ent,
+                                                   const uint32_t *__restrict__ aent, size_t aent_stride,
+                                                   const uint32_t *__restrict__ run_ids, const uint32_t *__restrict__ run_index,
+                                                   const uint32_t *__restrict__ mask, uint32_t mask_words,
+                                                   const uint32_t *__restrict__ known, const ConsensusLut *__restrict__ lut,
+                                                   int family, int wide, uint32_t n, uint32_t n_run,
+                                                   uint32_t *__restrict__ corr, uint32_t *__restrict__ corr_t)
+{
+    constexpr uint32_t RT = W >= 3 ? 32u : 64u;   // records per block (the tile stays below 64 KB of LDS)
+    __shared__ uint32_t tile[W][RT][65];   // [word][record in tile][run record in tile]
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * RT, h = blockIdx.y * 64u + lane;
+    const bool live_h = h < n_run;
+    const uint32_t hid = live_h ? run_ids[h] : 0u;
+    const uint32_t *hm = mask + (size_t)(live_h ? h : 0u) * mask_words;
+    for (uint32_t k = 0; k < RT / 4; ++k) {
+        const uint32_t rr = wv * (RT / 4) + k, r = r0 + rr;
+        uint32_t acc[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            acc[w] = 0;
+        if (r < n && live_h) {
+            const uint32_t end = off[r + 1];
+            for (uint32_t i = off[r]; i < end; ++i) {
+                const uint32_t c = (ent[i] & kSiteMask) >> 7;
+                if ((hm[c >> 5] >> (c & 31u)) & 1u) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        acc[w] -= aent[(size_t)w * aent_stride + i];
+                }
+            }
+            if (r > hid && run_index[r] != 0xFFFFFFFFu) {   // both run records: F over the chunks both leave out, once
+                const uint32_t *rm = mask + (size_t)run_index[r] * mask_words;
+                uint32_t kn = 0;
+                for (uint32_t q = 0; q < mask_words; ++q) {
+                    uint32_t m = hm[q] & rm[q];
+                    while (m) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        kn += known[32u * q + bit];
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    acc[w] += kn * lut->unit[family][wide][w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            tile[w][rr][lane] = acc[w];
+    }
+    __syncthreads();
+    const uint32_t h0 = blockIdx.y * 64u;
+    for (uint32_t e = threadIdx.x; e < RT * 64u; e += 256) {
+        // corr_t[w][r0 + a][h0 + b]: b runs along the run records
+        const uint32_t a = e >> 6, b = e & 63u;
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            if (r0 + a < n && h0 + b < n_run)
+                corr_t[((size_t)w * n + r0 + a) * n_run + h0 + b] = tile[w][a][b];
+        // corr[w][h0 + a2][r0 + b2]: b2 runs along the records
+        const uint32_t a2 = e / RT, b2 = e % RT;
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            if (h0 + a2 < n_run && r0 + b2 < n)
+                corr[((size_t)w * n_run + h0 + a2) * n + r0 + b2] = tile[w][b2][a2];
     }
 }
 
@@ -1016,6 +1262,12 @@ struct Pack {
 
 struct FWords {
     uint32_t w[kMaxWords];
+};
+
+// the run records' corrections as the pair kernel reads them (RunIndex; ids == NULL: none).  Square launches only.
+struct RunPair {
+    const uint32_t *index, *ids, *panel_first, *corr, *corr_t;
+    uint32_t n_run, n;
 };
 
 // which instantiations write their results in address-aligned quarters (see ALIGNED in the kernel): the single-word
@@ -1141,7 +1393,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     uint32_t n_sites, const ConsensusLut *__restrict__ lut, FWords fw,
     const ConsensusTile *__restrict__ tiles, void *__restrict__ out_v, const uint32_t *__restrict__ q_counts,
     const uint32_t *__restrict__ t_counts, uint32_t n_cols, uint32_t row_begin, uint64_t out_base, int square,
-    const void *__restrict__ hot)
+    const void *__restrict__ hot, RunPair rp)
 {
     using P = Pack<FAM, WIDE>;
     constexpr int W = P::W, NT = P::NT;
@@ -1343,6 +1595,37 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     if (i0 + 64 * u + lane < total)
                         apply(c[u] & (kPanelCols - 1u), c[u] >> kEntryShift, meta[u]);
             }
+        }
+    };
+    // ---- the run records' corrections of batch b (RunIndex): what the run COLUMNS of this panel add to each row of the
+    // batch (corr_t[row][h0 .. h1): contiguous), and, for a row that is a run record itself, what it adds to every
+    // column of the panel (corr[h][panel0 ..): contiguous).  Plain adds into the accumulators, like events.
+    const uint32_t run_h0 = rp.ids ? rp.panel_first[tile.panel] : 0u, run_h1 = rp.ids ? rp.panel_first[tile.panel + 1] : 0u;
+    auto apply_runs = [&](uint32_t b, uint32_t t, uint32_t nt) {   // thread t of nt
+        if (!rp.ids)
+            return;
+        const uint32_t q0 = tile.i0 + b * RB, nrows = min((uint32_t)RB, tile.i1 - q0);
+        uint32_t *bacc = acc + (UNI ? 0u : b & 1u) * ACC;
+        for (uint32_t rb = 0; rb < nrows; ++rb) {
+            const uint32_t q = q0 + rb;
+            uint32_t *racc = bacc + rb * W * kPanelCols;
+            for (uint32_t h = run_h0 + t; h < run_h1; h += nt) {
+                const uint32_t col = rp.ids[h] - panel0;
+                if (square && panel0 + col <= q)
+                    continue;
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    atomicAdd(&racc[w * kPanelCols + col], rp.corr_t[((size_t)w * rp.n + q) * rp.n_run + h]);
+            }
+            const uint32_t hq = rp.index[q];
+            if (hq != 0xFFFFFFFFu)
+                for (uint32_t k = t; k < pcols; k += nt) {
+                    if (square && panel0 + k <= q)
+                        continue;
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        atomicAdd(&racc[w * kPanelCols + k], rp.corr[((size_t)w * rp.n_run + hq) * rp.n + panel0 + k]);
+                }
         }
     };
     // ---- C of batch b from its accumulator buffer: constants, finalisation, canonical-order store
@@ -1593,6 +1876,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     s_cur = s_nx;
                 }
             }
+            apply_runs(b, threadIdx.x, 64u * kBlockWaves);
             DST_BATCH_BARRIER();
             output_batch(b);
             DST_BATCH_BARRIER();
@@ -1630,6 +1914,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                     }
 #endif
                 }
+                apply_runs(step, tid, kEventLanes);
                 // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
                 // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
                 // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
@@ -1855,7 +2140,7 @@ hipError_t launch_slot_fill(const DeviceSet &set, const uint4 *ref_planes, const
         constexpr uint32_t per_block = 4u * (64u / CLN);
         hipLaunchKernelGGL((slot_fill_kernel<CLN, decltype(wh)::value>), dim3((count + per_block - 1) / per_block), dim3(256), 0, stream,
                            set.rec.pre_slots, set.planes, ref_planes, hot_planes, n, nch, npad, rec_off, rec_ent, range_start, first,
-                           ent_cap);
+                           ent_cap, set.runs.active ? set.runs.index : nullptr, set.runs.active ? set.runs.state : nullptr);
     };
     using std::integral_constant;
     const uint32_t cln = count >= 32768 ? 8u : count >= 16384 ? 16u : 32u;
@@ -1922,18 +2207,66 @@ hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, uns
     return hipGetLastError();
 }
 
-hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const uint32_t *cnt_cold,
-                         const uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream)
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, uint32_t *cnt_cold,
+                         uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream, const RunIndex *runs,
+                         uint32_t max_run)
 {
-    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(1024), 0, stream, first_bad, stats, cnt_cold, cnt_hot, (uint32_t)n, report);
+    RunsArg ra{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (runs && runs->cnt_run)
+        ra = RunsArg{runs->cnt_run, runs->run_cold, runs->run_hot, runs->index, runs->ids, runs->state, max_run};
+    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(1024), 0, stream, first_bad, stats, cnt_cold, cnt_hot, (uint32_t)n, report, ra);
     return hipGetLastError();
 }
 
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream)
 {
+    RunConst rc{nullptr, 0, nullptr, nullptr, nullptr, 0};
+    if (set.runs.active)
+        rc = RunConst{set.runs.aent, set.runs.aent_cap / (kMaxWords * sizeof(uint32_t)), set.runs.index, set.runs.mask, set.runs.known,
+                      (uint32_t)set.runs.mask_words};
     hipLaunchKernelGGL(aconst_kernel, dim3((unsigned)((set.n + 3) / 4)), dim3(256), 0, stream, set.rec.off,
                        set.rec.ent, d_lut, family, wide ? 1 : 0, family_words(family, wide),
-                       (uint32_t)set.n, (uint32_t)set.npad, set.aconst);
+                       (uint32_t)set.n, (uint32_t)set.npad, set.aconst, rc);
+    return hipGetLastError();
+}
+
+// the run records' tables of one (family, packing) from the set's current lists: known sites per chunk, the panels'
+// first run records, then X's terms (corr_kernel); aconst_kernel must have run for the same (family, packing) first
+hipError_t launch_run_tables(const DeviceSet &set, int family, bool wide, bool without_hot, const ConsensusLut *d_lut, hipStream_t stream)
+{
+    const RunIndex &ru = set.runs;
+    const uint32_t n = (uint32_t)set.n, nch = (uint32_t)set.nchunks, n_panels = (uint32_t)((set.n + kPanelCols - 1) / kPanelCols);
+    hipLaunchKernelGGL(run_panels_kernel, dim3((n_panels + 256) / 256), dim3(256), 0, stream, ru.ids, ru.n_run, n_panels, ru.panel_first);
+    const uint32_t rt = family_words(family, wide) >= 3 ? 32u : 64u;   // corr_kernel's records per block
+    const dim3 grid((n + rt - 1) / rt, (ru.n_run + 63) / 64);
+    const size_t stride = ru.aent_cap / (kMaxWords * sizeof(uint32_t));
+#define DST_CORR(WW)                                                                                                              \
+    hipLaunchKernelGGL((corr_kernel<WW>), grid, dim3(256), 0, stream, set.rec.off, set.rec.ent, ru.aent, stride, ru.ids, ru.index, \
+                       ru.mask, (uint32_t)ru.mask_words, ru.known, d_lut, family, wide ? 1 : 0, n, ru.n_run, ru.corr, ru.corr_t)
+    switch (family_words(family, wide)) {
+    case 1: DST_CORR(1); break;
+    case 2: DST_CORR(2); break;
+    case 3: DST_CORR(3); break;
+    default: DST_CORR(4); break;
+    }
+#undef DST_CORR
+    (void)without_hot;
+    (void)nch;
+    return hipGetLastError();
+}
+
+hipError_t launch_run_masks(const DeviceSet &set, hipStream_t stream)
+{
+    const uint32_t total = set.runs.n_run * (uint32_t)set.runs.mask_words;
+    hipLaunchKernelGGL(run_masks_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, set.rec.pre_slots, set.runs.ids, set.runs.n_run,
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, (uint32_t)set.runs.mask_words, set.runs.mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_run_known(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(run_known_kernel, dim3((unsigned)((set.nchunks + 255) / 256)), dim3(256), 0, stream, ref_planes, hot_planes,
+                       (uint32_t)set.nchunks, set.runs.known);
     return hipGetLastError();
 }
 
@@ -1944,6 +2277,10 @@ hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStrea
 {
     const size_t smem = cpair_smem_words<FAM, WIDE, OUT, EW>() * sizeof(uint32_t) +
                         (OUT == DST_JC69 || OUT == DST_K80 || OUT == DST_TN93 ? 128 * sizeof(LogEntry) : 0);
+    RunPair rp{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (cl.square && cl.cols->runs.active && cl.cols->runs.n_run)
+        rp = RunPair{cl.cols->runs.index, cl.cols->runs.ids, cl.cols->runs.panel_first, cl.cols->runs.corr, cl.cols->runs.corr_t,
+                     cl.cols->runs.n_run, (uint32_t)cl.cols->n};
     auto kern = consensus_pair_kernel<FAM, WIDE, OUT, EW>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1955,7 +2292,7 @@ hipError_t launch_cpair_ew(const ConsensusLaunch &cl, const FWords &fw, hipStrea
                        cl.rows->aconst, (uint32_t)cl.rows->npad, cl.cols->site.inl, cl.cols->site.ent,
                        cl.cols->aconst, (uint32_t)cl.cols->npad, (uint32_t)(cl.cols->nchunks * kChunkSites), cl.d_lut,
                        fw, cl.d_tiles, cl.d_out, cl.rows->counts, cl.cols->counts, (uint32_t)cl.cols->n,
-                       (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0, cl.d_hot);
+                       (uint32_t)cl.row_begin, cl.out_base, cl.square ? 1 : 0, cl.d_hot, rp);
     return hipGetLastError();
 }
 

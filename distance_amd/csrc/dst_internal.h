@@ -98,6 +98,40 @@ struct RecordIndex {              // per record: the sites where it differs from
     bool ranges_valid = false;        // range_start holds the marks of THESE lists (a column set's site buckets can be built from them)
 };
 
+// ---- records with long runs of N (failed amplicons, partial genomes) ----------------------------------------------
+// Every site of a run is a difference from the reference sequence, and two such records share an event at every site
+// where their runs overlap: 5 % of 50,000 records half N cost the consensus path 59 ms instead of 2.  N contributes
+// NOTHING to any tally, whatever the other record holds, so a whole 128-site chunk of N in record t ("run chunk": the
+// reference has at least one known site there) can leave t's list, if every pair (q, t) is corrected for what the
+// identity then counts wrongly on those sites:
+//     T(q,t) = F + A'(q) + A'(t) + H(q,t) + X(q,t)          M_x = the run chunks of x (records with fewer than kRunMin keep
+//     A'(x)  = A(x: stripped list) - F(M_x)                        their entries: M_x is empty)
+//     X(q,t) = F(M_q n M_t) - A_q(M_t) - A_t(M_q)             A_q(M) = sum of a(e) over q's entries in the chunks of M
+// exact integers again (dst_consensus.hip: corr_kernel computes X's terms per (run record, record) once per set, the
+// pair kernel's event waves add them to the accumulators).  Records with runs: "run records" (hot records in DESIGN.md).
+constexpr uint32_t kRunMin = 4;            // run chunks (512 sites of N) that make a record a run record
+struct RunIndex {
+    uint32_t *cnt_run = nullptr;     // [n] run chunks of every record          } counted by the pack, one block with
+    uint32_t *run_cold = nullptr;    // [n] their entries at cold sites         } the arrays below: n_alloc records
+    uint32_t *run_hot = nullptr;     // [n] ... at hot sites
+    uint32_t *index = nullptr;       // [n] run record number of a record, or 0xFFFFFFFF
+    uint32_t *ids = nullptr;         // [n] the run records, ascending
+    uint32_t *mask = nullptr;        // [n_run][mask_words] bit c: chunk c of the run record is a run chunk (from the slots' flags)
+    uint32_t *known = nullptr;       // [nchunks] known reference sites of every chunk (cold sites only: without_hot lists)
+    uint32_t *panel_first = nullptr; // [n_panels + 1] first run record of every column panel
+    uint32_t *state = nullptr;       // device: [0] run records, [1] 1: stripping is on for this upload
+    uint32_t *aent = nullptr;        // [kMaxWords][entries] a-words of every list entry (aconst_kernel), what corr_kernel sums
+    uint32_t *corr = nullptr;        // [words][n_run][n]   X's terms by (run record, record) ...
+    uint32_t *corr_t = nullptr;      // [words][n][n_run]   ... and transposed
+    size_t n_alloc = 0, mask_words = 0, mask_cap = 0, known_cap = 0, panel_cap = 0, aent_cap = 0, corr_cap = 0, corr_t_cap = 0;   // (capacities in bytes)
+    uint64_t removed = 0;            // entries the run records' lists lost (host copy: rescales the sample's statistics)
+    uint32_t n_run = 0;              // host copy (0: no run records, or stripping off)
+    bool active = false;             // this upload's lists are stripped of the run records' run chunks
+    int corr_family = -1;            // what corr / corr_t hold (like aconst)
+    bool corr_wide = false, corr_without_hot = false;
+    uint64_t corr_epoch = 0;
+};
+
 struct SiteIndex {                // the same entries of a column set by (site, panel of kPanelCols records)
     // [n_sites * n_panels] 32 bytes per bucket = 16 halfwords: [0] entries in the bucket, then up to kInlineEvents
     // entries as record-in-panel | nibble << 11.  The pair kernel reads THIS: one request per (row entry, panel)
@@ -128,6 +162,7 @@ struct DeviceSet {
     ConsensusRef ref;
     RecordIndex rec;
     SiteIndex site;
+    RunIndex runs;
     uint32_t *aconst = nullptr;   // [kMaxWords][npad] packed A_k words of one measure family (see the key below)
     size_t aconst_cap = 0;
     int aconst_family = -1;       // what `aconst` currently holds: family, packing, and the lists it was summed from
@@ -250,10 +285,19 @@ size_t scan_tmp_words(size_t n);
 hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStream_t stream, const uint32_t *src0 = nullptr,
                                  const uint32_t *src1 = nullptr, uint32_t *zero = nullptr, uint32_t n_zero = 0);
 hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const ConsensusLut *d_lut, hipStream_t stream);
-constexpr int kReportWords = 11;   // [0] first invalid byte, [1..8] the sample's statistics, [9..10] list totals
-// cnt_cold / cnt_hot (may be NULL): the pack's list lengths, summed into words 9 and 10
-hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, const uint32_t *cnt_cold,
-                         const uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream);
+// run records (RunIndex): the known reference sites per chunk (hot_planes != NULL: cold sites only), and the correction
+// tables of one (family, packing) — after launch_aconst for the same, which leaves the entries' a-words in runs.aent
+hipError_t launch_run_known(const DeviceSet &set, const uint4 *ref_planes, const uint4 *hot_planes, hipStream_t stream);
+hipError_t launch_run_masks(const DeviceSet &set, hipStream_t stream);   // runs.mask from the slots' run-chunk flags
+hipError_t launch_run_tables(const DeviceSet &set, int family, bool wide, bool without_hot, const ConsensusLut *d_lut, hipStream_t stream);
+constexpr int kReportWords = 13;   // [0] first invalid byte, [1..8] the sample's statistics, [9..10] list totals, [11] run records, [12] entries their lists lost
+// cnt_cold / cnt_hot (may be NULL): the pack's list lengths, summed into words 9 and 10.  runs: the pack's run-chunk
+// counters — records with kRunMin run chunks and more become run records (numbered in runs->index / ids, word 11 = how
+// many; 0 when there are more than max_run: stripping off), every other record gets its run chunks' entries back into
+// its list length
+hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, uint32_t *cnt_cold,
+                         uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream, const RunIndex *runs = nullptr,
+                         uint32_t max_run = 0);
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],
@@ -271,6 +315,8 @@ struct PackLists {
     unsigned long long max_dev_sum;            // count only while stats[1] <= this (high-diversity sets go dense anyway)
     uint32_t *cnt_cold, *cnt_hot;              // [n], zeroed
     uint4 *slots;                              // [nchunks][npad] the differences of every (record, chunk), see pack_kernel
+    // run chunks (RunIndex; all NULL: not looked for): counted apart and flagged in the slot
+    uint32_t *cnt_run, *run_cold, *run_hot;
 };
 // rec_begin / rec_end: only those records are packed (one rank's share of a set: dst_upload_shared)
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,

@@ -193,7 +193,25 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                 cold += __builtin_popcount(d[w] & ~hw[w]);
                 hot += __builtin_popcount(d[w] & hw[w]);
             }
-            if (cold + hot) {
+            // a run chunk: 128 sites of N (N, -, ?) where the reference has a known base — its entries are counted apart,
+            // the slot notes it: whether they stay in the list is decided once the record's run
+            // chunks are counted (finish_kernel, slot_fill_kernel; dst_internal.h: RunIndex)
+            bool run_chunk = false;
+            if (lists.cnt_run && cold + hot) {
+                uint32_t all_n = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    all_n &= out[PL_A][w] & out[PL_G][w] & out[PL_C][w] & out[PL_T][w];
+                run_chunk = all_n == 0xFFFFFFFFu;   // (cold + hot != 0: the reference is not all N-class here)
+            }
+            if (run_chunk) {
+                atomicAdd(&lists.cnt_run[s], 1u);
+                if (cold)
+                    atomicAdd(&lists.run_cold[s], cold);
+                if (hot)
+                    atomicAdd(&lists.run_hot[s], hot);
+                slot[0] = min(cold + hot, 255u) | 0x100u;
+            } else if (cold + hot) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     uint32_t m = d[w];
@@ -734,7 +752,7 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
     const uint32_t last = (uint32_t)(rec_end >= set.n ? set.npad : rec_end);
     if (last <= first)
         return hipSuccess;
-    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
                           (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);

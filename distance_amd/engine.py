@@ -160,6 +160,12 @@ class Engine:
     def last_path(self) -> str:
         return {1: "dense", 2: "consensus", 3: "hybrid"}.get(self._lib.dst_last_path(self._h), "?")
 
+    def run_records(self, slot: int = 0) -> tuple[int, int]:
+        """(records the consensus path treats as run records — long runs of N left out of their lists —, entries removed)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.dst_run_records(self._h, slot, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     # ---- per-alignment precompute of -m n (src/lib.rs:223-231) ------------------------------
     def consensus(self, both_slots: bool = False) -> np.ndarray:
         """consensus() of src/fastaio.rs:289-336 over slot 0 (and slot 1), computed on the device."""

@@ -122,6 +122,12 @@ int dst_set_prep_threshold(dst_ctx *ctx, double site_comparisons);
  *                      says is fastest. */
 typedef enum { DST_PATH_AUTO = 0, DST_PATH_DENSE = 1, DST_PATH_CONSENSUS = 2, DST_PATH_HYBRID = 3 } dst_path;
 int dst_set_path(dst_ctx *ctx, int path);
+/* Records with long runs of N (failed amplicons, partial genomes; N adds nothing to any tally: src/measures.rs:17, 59-66,
+ * 89-107, 160-175) in the set of `slot`: how many the consensus path currently treats as "run records" — their chunks
+ * of 128 N sites are left out of the difference lists and every pair with such a record is corrected exactly
+ * (DESIGN.md 3b'') — and how many list entries that removed.  0 when the set has none, too many (more than a third of the
+ * records), or its lists were not built by the upload's fused preparation.  Diagnostic; the results do not depend on it. */
+int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_t *entries_removed);
 /* DST_PATH_DENSE, DST_PATH_CONSENSUS or DST_PATH_HYBRID: what the most recent run on this context used */
 int dst_last_path(const dst_ctx *ctx);
 
