@@ -70,7 +70,7 @@ void free_set(DeviceSet &s)
 {
     void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.range_start, s.rec.pre_cold, s.rec.pre_slots,
                     s.site.inl, s.site.ent, s.aconst, s.runs.index, s.runs.mask, s.runs.known, s.runs.panel_first, s.runs.state,
-                    s.runs.aent, s.runs.corr, s.runs.corr_t};   // (runs.cnt_run / run_cold / run_hot / ids live in the pre_cold and index blocks)
+                    s.runs.aent, s.runs.corr, s.runs.corr_t, s.runs.s7};   // (runs.cnt_run / run_cold / run_hot / ids live in the pre_cold and index blocks)
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -655,6 +655,8 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
             rc = ensure_bytes(ctx, (void **)&ru.corr, &ru.corr_cap, words * ru.n_run * s.n * sizeof(uint32_t));
         if (!rc)
             rc = ensure_bytes(ctx, (void **)&ru.corr_t, &ru.corr_t_cap, words * ru.n_run * s.n * sizeof(uint32_t));
+        if (!rc)   // the records' per-chunk sums in 7-bit pieces: the B operand of the correction tables' matrix product
+            rc = ensure_bytes(ctx, (void **)&ru.s7, &ru.s7_cap, words * 5 * s.n * 32 * ru.mask_words + 64);
         if (rc)
             return rc;
     }
@@ -926,7 +928,9 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             const double S = (double)std::max<uint64_t>(st[3], 1);
             const double f = run_scale(cols);
             const double events = f * f * (double)(hybrid ? st[7] : st[2]) / (S * S), list = f * (double)(hybrid ? st[6] : st[1]) / S;
-            cl.heavy_events = events > 1.0 ? 2 : events > 0.5 || list > 100.0 ? 1 : 0;
+            // (a run record's row or column adds one word per pair from the correction tables: like an event, a cheaper one)
+            const double run_adds = cols.runs.active && square ? 2.0 * cols.runs.n_run / std::max<double>((double)cols.n, 1.0) : 0.0;
+            cl.heavy_events = events + run_adds > 1.0 ? 2 : events + run_adds > 0.3 || list > 100.0 ? 1 : 0;
         }
         ctx->last_path = path;
         if (ntiles) {

@@ -1137,78 +1137,194 @@ __global__ __launch_bounds__(256) void run_panels_kernel(const uint32_t *__restr
 
 // X's terms (RunIndex) for every (run record h, record r):
 //     C(h, r) = - A_r(M_h)  [r's list entries in h's run chunks]  +  F(M_h n M_r) if r is a run record with a higher id
-// so that a pair (q, t) gets C(t, q) when t is a run record and C(q, t) when q is one — both terms once, the F term once.
-// One block = 64 records x 64 run records: wave w takes 16 of the records, lane = run record; a record's entries are the
-// same for all lanes (broadcast loads), the run record's mask word is one gathered load per entry.  The tile leaves
-// through LDS in both orientations: corr[w][h][r] (what a run ROW adds to a panel) and corr_t[w][r][h] (what the run
-// COLUMNS of a panel add to a row).
+// — in the table the run ROWS read (corr[h][r]: what row h adds to column r) but not in the one the run COLUMNS read
+// (corr_t[r][h]): a pair (q, t) gets corr_t[q][t's number] when t is a run record and corr[q's number][t] when q is one,
+// so both A terms once and the F term once.
+// A_r(M_h) = sum over chunks c of [c in M_h] x S(r, c), S(r, c) = the a-words of r's entries in chunk c: a 0/1 matrix
+// (run records x chunks) times a matrix of per-chunk sums (chunks x records).  That IS a matrix product, of integers,
+// and at 4,000 run records x 20,000 records x 235 chunks the VALU forms of it (a test per list entry and run record:
+// 3.3 ms; LDS atomics per incidence: 1.6 ms) cost more than the pair kernel — so it goes through the matrix cores:
+// v_mfma_i32_32x32x32_i8, the 32-bit sums cut into five 7-bit pieces (exact: a piece is below 128, 256 chunks of them
+// stay far inside an int32; the pieces' results are shifted back together modulo 2^32, like the packed tallies).
+constexpr int kSumPieces = 5;   // 7 + 7 + 7 + 7 + 4 bits of a 32-bit sum
+
+// S7[w][piece][record][Kpad]: the per-chunk sums of every record's a-words, in 7-bit pieces (bytes); Kpad = 32 mask_words
+// fold (run_index != NULL): a run record's sums also lose known[c] x unit on its own run chunks — then the product with
+// another run record's mask carries the F term of the two (+F after the sign flip).  The table the run ROWS read is built
+// from the folded sums, the table the run COLUMNS read from the plain ones: a pair of two run records meets the F term once.
 template <int W>
-__global__ __launch_bounds__(256) void corr_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ent,
-                                                   const uint32_t *__restrict__ aent, size_t aent_stride,
-                                                   const uint32_t *__restrict__ run_ids, const uint32_t *__restrict__ run_index,
-                                                   const uint32_t *__restrict__ mask, uint32_t mask_words,
-                                                   const uint32_t *__restrict__ known, const ConsensusLut *__restrict__ lut,
-                                                   int family, int wide, uint32_t n, uint32_t n_run,
-                                                   uint32_t *__restrict__ corr, uint32_t *__restrict__ corr_t)
+__global__ __launch_bounds__(256) void chunk_sums_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ent,
+                                                         const uint32_t *__restrict__ aent, size_t aent_stride, uint32_t n,
+                                                         uint32_t kpad, uint8_t *__restrict__ s7,
+                                                         const uint32_t *__restrict__ run_index, const uint32_t *__restrict__ mask,
+                                                         const uint32_t *__restrict__ known, const ConsensusLut *__restrict__ lut,
+                                                         int family, int wide)
 {
-    constexpr uint32_t RT = W >= 3 ? 32u : 64u;   // records per block (the tile stays below 64 KB of LDS)
-    __shared__ uint32_t tile[W][RT][65];   // [word][record in tile][run record in tile]
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t r0 = blockIdx.x * RT, h = blockIdx.y * 64u + lane;
-    const bool live_h = h < n_run;
-    const uint32_t hid = live_h ? run_ids[h] : 0u;
-    const uint32_t *hm = mask + (size_t)(live_h ? h : 0u) * mask_words;
-    for (uint32_t k = 0; k < RT / 4; ++k) {
-        const uint32_t rr = wv * (RT / 4) + k, r = r0 + rr;
-        uint32_t acc[W];
+    extern __shared__ uint32_t srow[];   // [4 waves][W][kpad]
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, r = blockIdx.x * 4u + wv;
+    uint32_t *mine = srow + (size_t)wv * W * kpad;
+    for (uint32_t c = lane; c < W * kpad; c += 64)
+        mine[c] = 0;
+    if (r >= n)
+        return;
+    const uint32_t end = off[r + 1];
+    for (uint32_t i = off[r] + lane; i < end; i += 64) {
+        const uint32_t c = (ent[i] & kSiteMask) >> 7;
 #pragma unroll
         for (int w = 0; w < W; ++w)
-            acc[w] = 0;
-        if (r < n && live_h) {
-            const uint32_t end = off[r + 1];
-            for (uint32_t i = off[r]; i < end; ++i) {
-                const uint32_t c = (ent[i] & kSiteMask) >> 7;
-                if ((hm[c >> 5] >> (c & 31u)) & 1u) {
-#pragma unroll
-                    for (int w = 0; w < W; ++w)
-                        acc[w] -= aent[(size_t)w * aent_stride + i];
-                }
-            }
-            if (r > hid && run_index[r] != 0xFFFFFFFFu) {   // both run records: F over the chunks both leave out, once
-                const uint32_t *rm = mask + (size_t)run_index[r] * mask_words;
-                uint32_t kn = 0;
-                for (uint32_t q = 0; q < mask_words; ++q) {
-                    uint32_t m = hm[q] & rm[q];
-                    while (m) {
-                        const uint32_t bit = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1;
-                        kn += known[32u * q + bit];
-                    }
-                }
+            atomicAdd(&mine[w * kpad + c], aent[(size_t)w * aent_stride + i]);
+    }
+    if (run_index && run_index[r] != 0xFFFFFFFFu) {
+        const uint32_t *m = mask + (size_t)run_index[r] * (kpad / 32u);
+        for (uint32_t c = lane; c < kpad; c += 64)
+            if ((m[c >> 5] >> (c & 31u)) & 1u) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    acc[w] += kn * lut->unit[family][wide][w];
+                    mine[w * kpad + c] -= known[c] * lut->unit[family][wide][w];
+            }
+    }
+    // (one wave writes and reads its own LDS rows: in order)
+    for (uint32_t c4 = lane * 4; c4 < kpad; c4 += 256) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t v[4] = {mine[w * kpad + c4], mine[w * kpad + c4 + 1], mine[w * kpad + c4 + 2], mine[w * kpad + c4 + 3]};
+#pragma unroll
+            for (int p = 0; p < kSumPieces; ++p) {
+                const uint32_t sh = 7u * p;
+                const uint32_t packed = ((v[0] >> sh) & 127u) | ((v[1] >> sh) & 127u) << 8 | ((v[2] >> sh) & 127u) << 16 |
+                                        ((v[3] >> sh) & 127u) << 24;
+                *reinterpret_cast<uint32_t *>(s7 + (((size_t)w * kSumPieces + p) * n + r) * kpad + c4) = packed;
             }
         }
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-            tile[w][rr][lane] = acc[w];
     }
-    __syncthreads();
-    const uint32_t h0 = blockIdx.y * 64u;
-    for (uint32_t e = threadIdx.x; e < RT * 64u; e += 256) {
-        // corr_t[w][r0 + a][h0 + b]: b runs along the run records
-        const uint32_t a = e >> 6, b = e & 63u;
+}
+
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+typedef int v16i32_t __attribute__((ext_vector_type(16)));
+
+// 16 mask bits -> 16 bytes of 0 / 1 (the A operand's fragment: a lane's 16 consecutive k)
+__device__ __forceinline__ v4i32_t spread16(uint32_t bits)
+{
+    v4i32_t o;
+    o.x = (int)(((bits & 15u) * 0x00204081u) & 0x01010101u);
+    o.y = (int)((((bits >> 4) & 15u) * 0x00204081u) & 0x01010101u);
+    o.z = (int)((((bits >> 8) & 15u) * 0x00204081u) & 0x01010101u);
+    o.w = (int)((((bits >> 12) & 15u) * 0x00204081u) & 0x01010101u);
+    return o;
+}
+
+// One block = 128 run records x 128 records: each of the 4 waves 32 records against four 32-run-record sub-tiles.  A = the run records' masks as 0/1
+// bytes, B = one 7-bit piece of the records' per-chunk sums; lane l holds row / column l & 31 and the 16 consecutive
+// k of half l >> 5 of every 32-chunk step, in both operands (the same k in the same place is all the sum needs).
+// D (dtype-independent on gfx950): column = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+// TRANSPOSED: the result goes to corr_t[w][record][run record] (through LDS: a row of 32 run records per record), else to
+// corr[w][run record][record] (32 consecutive records per lane group as the accumulators lie).
+template <int W, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void corr_mfma_kernel(const uint32_t *__restrict__ mask, uint32_t mask_words,
+                                                        const uint8_t *__restrict__ s7, uint32_t n, uint32_t n_run,
+                                                        uint32_t *__restrict__ table)
+{
+    // a wave = 32 records x kRunTiles x 32 run records: the B fragment (16 bytes of a record's sums per lane, rows 32 k
+    // apart: half a cache line of use per line fetched) is loaded once and meets kRunTiles mask fragments
+    constexpr int kRunTiles = 4;
+    __shared__ uint32_t turn[TRANSPOSED ? 4 : 1][TRANSPOSED ? 32 : 1][33];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, half = lane >> 5, idx = lane & 31u;
+    const uint32_t r_col = blockIdx.x * 128u + wv * 32u + idx;     // this lane's record (B's column)
+    const uint32_t h_base = blockIdx.y * (32u * kRunTiles);
+    const uint32_t kpad = 32u * mask_words;
+    const bool b_live = r_col < n;
+    const uint32_t *mrow[kRunTiles];
+    bool a_live[kRunTiles];
 #pragma unroll
-        for (int w = 0; w < W; ++w)
-            if (r0 + a < n && h0 + b < n_run)
-                corr_t[((size_t)w * n + r0 + a) * n_run + h0 + b] = tile[w][a][b];
-        // corr[w][h0 + a2][r0 + b2]: b2 runs along the records
-        const uint32_t a2 = e / RT, b2 = e % RT;
+    for (int t = 0; t < kRunTiles; ++t) {
+        const uint32_t h_row = h_base + 32u * t + idx;             // this lane's run record of sub-tile t (A's row)
+        a_live[t] = h_row < n_run;
+        mrow[t] = mask + (size_t)min(h_row, n_run - 1u) * mask_words;
+    }
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        uint32_t out[kRunTiles][16];
 #pragma unroll
-        for (int w = 0; w < W; ++w)
-            if (h0 + a2 < n_run && r0 + b2 < n)
-                corr[((size_t)w * n_run + h0 + a2) * n + r0 + b2] = tile[w][b2][a2];
+        for (int t = 0; t < kRunTiles; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                out[t][v] = 0;
+#pragma unroll 1
+        for (int p = 0; p < kSumPieces; ++p) {
+            const uint8_t *brow = s7 + (((size_t)w * kSumPieces + p) * n + min(r_col, n - 1u)) * kpad + 16u * half;
+            v16i32_t acc[kRunTiles];
+#pragma unroll
+            for (int t = 0; t < kRunTiles; ++t)
+                acc[t] = v16i32_t{};
+            // the operands of step ks + 1 are loaded before the MFMAs of step ks are issued: with four 16-register
+            // accumulators a SIMD holds two or three of these waves, too few to hide a load per step behind each other
+            // (every load unconditional, from a clamped address, its value dropped by a select afterwards: written as
+            // conditional loads each became a branch with its own wait — five serial memory latencies per step)
+            auto load_step = [&](uint32_t ks, uint4 &bv, uint32_t (&bits)[kRunTiles]) {
+                const uint32_t kc = min(ks, mask_words - 1u);
+                const uint4 raw = *reinterpret_cast<const uint4 *>(brow + 32u * kc);
+                uint32_t word[kRunTiles];
+#pragma unroll
+                for (int t = 0; t < kRunTiles; ++t)
+                    word[t] = mrow[t][kc];
+                const bool on = ks < mask_words;
+                bv.x = (b_live && on) ? raw.x : 0u;
+                bv.y = (b_live && on) ? raw.y : 0u;
+                bv.z = (b_live && on) ? raw.z : 0u;
+                bv.w = (b_live && on) ? raw.w : 0u;
+#pragma unroll
+                for (int t = 0; t < kRunTiles; ++t)
+                    bits[t] = (a_live[t] && on) ? (word[t] >> (16u * half)) & 0xFFFFu : 0u;
+            };
+            // two operand sets in turn (no copies between them): the loads of one are in flight while the MFMAs of the other
+            // issue, and the wait in front of those MFMAs is for the OLDER loads only
+            auto mfma_step = [&](const uint4 &bv, const uint32_t (&bits)[kRunTiles]) {
+                v4i32_t bf;
+                bf.x = (int)bv.x, bf.y = (int)bv.y, bf.z = (int)bv.z, bf.w = (int)bv.w;
+#pragma unroll
+                for (int t = 0; t < kRunTiles; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(spread16(bits[t]), bf, acc[t], 0, 0, 0);
+            };
+            uint4 bv_a, bv_b;
+            uint32_t bits_a[kRunTiles], bits_b[kRunTiles];
+            load_step(0, bv_a, bits_a);
+            for (uint32_t ks = 0; ks < mask_words; ks += 2) {
+                load_step(ks + 1, bv_b, bits_b);
+                mfma_step(bv_a, bits_a);
+                load_step(ks + 2, bv_a, bits_a);
+                mfma_step(bv_b, bits_b);   // (past the last step: zeros)
+            }
+#pragma unroll
+            for (int t = 0; t < kRunTiles; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    out[t][v] += (uint32_t)acc[t][v] << (7u * p);
+        }
+#pragma unroll
+        for (int t = 0; t < kRunTiles; ++t) {
+            const uint32_t h0 = h_base + 32u * t;
+            if (h0 >= n_run)   // (uniform)
+                continue;
+            if constexpr (!TRANSPOSED) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const uint32_t h = h0 + (v & 3u) + 8u * (v >> 2) + 4u * half;
+                    if (b_live && h < n_run)
+                        table[((size_t)w * n_run + h) * n + r_col] = 0u - out[t][v];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    turn[wv][idx][(v & 3u) + 8u * (v >> 2) + 4u * half] = 0u - out[t][v];   // [record][run record]
+                // (a wave's own tile: LDS operations of one wave complete in order)
+                for (uint32_t e = lane; e < 32u * 32u; e += 64) {
+                    const uint32_t rr = e >> 5, hh = e & 31u;
+                    const uint32_t r = blockIdx.x * 128u + wv * 32u + rr, h = h0 + hh;
+                    if (r < n && h < n_run)
+                        table[((size_t)w * n + r) * n_run + h] = turn[wv][rr][hh];
+                }
+            }
+        }
     }
 }
 
@@ -1609,22 +1725,45 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
         for (uint32_t rb = 0; rb < nrows; ++rb) {
             const uint32_t q = q0 + rb;
             uint32_t *racc = bacc + rb * W * kPanelCols;
-            for (uint32_t h = run_h0 + t; h < run_h1; h += nt) {
-                const uint32_t col = rp.ids[h] - panel0;
-                if (square && panel0 + col <= q)
-                    continue;
+            // (four loads in flight per lane: the values are independent, only the adds are ordered)
+            constexpr uint32_t UNR = 4;
+            for (uint32_t h0 = run_h0 + t; h0 < run_h1; h0 += nt * UNR) {
+                uint32_t col[UNR], v[UNR][W];
 #pragma unroll
-                for (int w = 0; w < W; ++w)
-                    atomicAdd(&racc[w * kPanelCols + col], rp.corr_t[((size_t)w * rp.n + q) * rp.n_run + h]);
-            }
-            const uint32_t hq = rp.index[q];
-            if (hq != 0xFFFFFFFFu)
-                for (uint32_t k = t; k < pcols; k += nt) {
-                    if (square && panel0 + k <= q)
+                for (uint32_t u = 0; u < UNR; ++u) {
+                    const uint32_t h = h0 + nt * u;
+                    col[u] = h < run_h1 ? rp.ids[h] - panel0 : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        v[u][w] = h < run_h1 ? rp.corr_t[((size_t)w * rp.n + q) * rp.n_run + h] : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UNR; ++u) {
+                    if (col[u] == 0xFFFFFFFFu || (square && panel0 + col[u] <= q))
                         continue;
 #pragma unroll
                     for (int w = 0; w < W; ++w)
-                        atomicAdd(&racc[w * kPanelCols + k], rp.corr[((size_t)w * rp.n_run + hq) * rp.n + panel0 + k]);
+                        atomicAdd(&racc[w * kPanelCols + col[u]], v[u][w]);
+                }
+            }
+            const uint32_t hq = rp.index[q];
+            if (hq != 0xFFFFFFFFu)
+                for (uint32_t k0 = t; k0 < pcols; k0 += nt * UNR) {
+                    uint32_t v[UNR][W];
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                            v[u][w] = k0 + nt * u < pcols ? rp.corr[((size_t)w * rp.n_run + hq) * rp.n + panel0 + k0 + nt * u] : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; ++u) {
+                        const uint32_t k = k0 + nt * u;
+                        if (k >= pcols || (square && panel0 + k <= q))
+                            continue;
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                            atomicAdd(&racc[w * kPanelCols + k], v[u][w]);
+                    }
                 }
         }
     };
@@ -2230,20 +2369,36 @@ hipError_t launch_aconst(const DeviceSet &set, int family, bool wide, const Cons
     return hipGetLastError();
 }
 
-// the run records' tables of one (family, packing) from the set's current lists: known sites per chunk, the panels'
-// first run records, then X's terms (corr_kernel); aconst_kernel must have run for the same (family, packing) first
+// the run records' tables of one (family, packing) from the set's current lists: the panels' first run records, the
+// per-chunk sums in 7-bit pieces, then X's terms by the matrix cores (corr_mfma_kernel) and the run x run F terms;
+// aconst_kernel must have run for the same (family, packing) first (it leaves the entries' a-words in runs.aent)
 hipError_t launch_run_tables(const DeviceSet &set, int family, bool wide, bool without_hot, const ConsensusLut *d_lut, hipStream_t stream)
 {
     const RunIndex &ru = set.runs;
-    const uint32_t n = (uint32_t)set.n, nch = (uint32_t)set.nchunks, n_panels = (uint32_t)((set.n + kPanelCols - 1) / kPanelCols);
+    const uint32_t n = (uint32_t)set.n, n_panels = (uint32_t)((set.n + kPanelCols - 1) / kPanelCols);
+    const uint32_t mw = (uint32_t)ru.mask_words, kpad = 32u * mw;
+    const int words = family_words(family, wide);
     hipLaunchKernelGGL(run_panels_kernel, dim3((n_panels + 256) / 256), dim3(256), 0, stream, ru.ids, ru.n_run, n_panels, ru.panel_first);
-    const uint32_t rt = family_words(family, wide) >= 3 ? 32u : 64u;   // corr_kernel's records per block
-    const dim3 grid((n + rt - 1) / rt, (ru.n_run + 63) / 64);
     const size_t stride = ru.aent_cap / (kMaxWords * sizeof(uint32_t));
-#define DST_CORR(WW)                                                                                                              \
-    hipLaunchKernelGGL((corr_kernel<WW>), grid, dim3(256), 0, stream, set.rec.off, set.rec.ent, ru.aent, stride, ru.ids, ru.index, \
-                       ru.mask, (uint32_t)ru.mask_words, ru.known, d_lut, family, wide ? 1 : 0, n, ru.n_run, ru.corr, ru.corr_t)
-    switch (family_words(family, wide)) {
+    const dim3 grid((n + 127) / 128, (ru.n_run + 127) / 128);   // corr_mfma_kernel: 128 records x 128 run records per block
+#define DST_CORR(WW)                                                                                                                  \
+    do {                                                                                                                              \
+        const size_t lds = (size_t)4 * WW * kpad * sizeof(uint32_t);                                                                  \
+        if (lds > 64 * 1024) {                                                                                                        \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_sums_kernel<WW>),                          \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+            if (ea != hipSuccess)                                                                                                     \
+                return ea;                                                                                                            \
+        }                                                                                                                             \
+        /* the run COLUMNS' table from the plain sums, the run ROWS' table from the sums with the F terms folded in */              \
+        hipLaunchKernelGGL((chunk_sums_kernel<WW>), dim3((n + 3) / 4), dim3(256), lds, stream, set.rec.off, set.rec.ent, ru.aent,     \
+                           stride, n, kpad, ru.s7, nullptr, nullptr, nullptr, d_lut, family, wide ? 1 : 0);                           \
+        hipLaunchKernelGGL((corr_mfma_kernel<WW, true>), grid, dim3(256), 0, stream, ru.mask, mw, ru.s7, n, ru.n_run, ru.corr_t);     \
+        hipLaunchKernelGGL((chunk_sums_kernel<WW>), dim3((n + 3) / 4), dim3(256), lds, stream, set.rec.off, set.rec.ent, ru.aent,     \
+                           stride, n, kpad, ru.s7, ru.index, ru.mask, ru.known, d_lut, family, wide ? 1 : 0);                         \
+        hipLaunchKernelGGL((corr_mfma_kernel<WW, false>), grid, dim3(256), 0, stream, ru.mask, mw, ru.s7, n, ru.n_run, ru.corr);      \
+    } while (0)
+    switch (words) {
     case 1: DST_CORR(1); break;
     case 2: DST_CORR(2); break;
     case 3: DST_CORR(3); break;
@@ -2251,7 +2406,6 @@ hipError_t launch_run_tables(const DeviceSet &set, int family, bool wide, bool w
     }
 #undef DST_CORR
     (void)without_hot;
-    (void)nch;
     return hipGetLastError();
 }
 

@@ -120,10 +120,11 @@ struct RunIndex {
     uint32_t *known = nullptr;       // [nchunks] known reference sites of every chunk (cold sites only: without_hot lists)
     uint32_t *panel_first = nullptr; // [n_panels + 1] first run record of every column panel
     uint32_t *state = nullptr;       // device: [0] run records, [1] 1: stripping is on for this upload
-    uint32_t *aent = nullptr;        // [kMaxWords][entries] a-words of every list entry (aconst_kernel), what corr_kernel sums
+    uint32_t *aent = nullptr;        // [kMaxWords][entries] a-words of every list entry (aconst_kernel), what the tables sum
+    uint8_t *s7 = nullptr;           // [words][5][n][32 mask_words] every record's per-chunk sums of them, in 7-bit pieces
     uint32_t *corr = nullptr;        // [words][n_run][n]   X's terms by (run record, record) ...
     uint32_t *corr_t = nullptr;      // [words][n][n_run]   ... and transposed
-    size_t n_alloc = 0, mask_words = 0, mask_cap = 0, known_cap = 0, panel_cap = 0, aent_cap = 0, corr_cap = 0, corr_t_cap = 0;   // (capacities in bytes)
+    size_t n_alloc = 0, mask_words = 0, mask_cap = 0, known_cap = 0, panel_cap = 0, aent_cap = 0, corr_cap = 0, corr_t_cap = 0, s7_cap = 0;   // (capacities in bytes)
     uint64_t removed = 0;            // entries the run records' lists lost (host copy: rescales the sample's statistics)
     uint32_t n_run = 0;              // host copy (0: no run records, or stripping off)
     bool active = false;             // this upload's lists are stripped of the run records' run chunks
