@@ -945,10 +945,32 @@ __global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *
             base_s = 0;
         unsigned long long w2[4] = {0, 0, 0, 0};
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        if (!strip) {
+            // no run records (a few terminal gaps that fill a chunk: the usual case): every run chunk's entries go back,
+            // in any order — eight records per thread and round, their loads in flight together
+            for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
+                uint32_t ch[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u)
+                    ch[u] = i0 + 1024 * u < n ? runs.cnt_run[i0 + 1024 * u] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u)
+                    if (ch[u]) {
+                        const uint32_t i = i0 + 1024 * u, rc = runs.run_cold[i], rh = runs.run_hot[i];
+                        if (rc)
+                            cnt0[i] += rc;
+                        if (rh)
+                            cnt1[i] += rh;
+                        w2[0] += rc;
+                        w2[1] += rh;
+                    }
+            }
+        }
+        for (uint32_t i0 = 0; strip && i0 < n; i0 += 1024) {
             const uint32_t i = i0 + tid;
-            const bool is_run = i < n && strip && runs.cnt_run[i] >= kRunMin;
-            if (i < n) {
+            const uint32_t chunks = i < n ? runs.cnt_run[i] : 0u;
+            const bool is_run = strip && chunks >= kRunMin;
+            if (chunks) {   // (most records have no run chunk at all: nothing to read, nothing to give back)
                 const uint32_t rc = runs.run_cold[i], rh = runs.run_hot[i];
                 if (!is_run) {
                     if (rc)

@@ -14,7 +14,8 @@ src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 OURS = ("consensus_pair_kernel", "pair_kernel", "finalize_kernel", "pack_kernel", "counts_kernel", "index_kernel",
         "ref_sample_kernel", "hot_list_kernel", "site_bucket_kernel", "slot_fill_kernel", "derive_kernel", "sum2_u32_kernel", "add_u32_kernel", "aconst_kernel",
-        "scan_block_kernel", "scan_add_kernel", "compact_kernel", "report_kernel")
+        "scan_block_kernel", "scan_add_kernel", "scan_small_kernel", "compact_kernel", "report_kernel", "chunk_sums_kernel", "corr_mfma_kernel",
+        "run_masks_kernel", "run_known_kernel", "run_panels_kernel", "pack_nibbles_kernel", "number_kernel", "line_kernel")
 
 
 def short(name):
@@ -29,7 +30,7 @@ lines = []
 for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     rows = list(csv.DictReader(open(path)))
     lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
-    lines.append("# (default workload 50,000 x 30,000: main leg raw/auto, then legs dense raw, tn93 auto, tn93 dense; 7 launches each)")
+    lines.append("# (default workload 50,000 x 30,000: main leg raw/auto, then legs dense raw, tn93 auto, tn93 dense, clades, nruns; the verify passes' dense slabs included)")
     lines.append(f"{'kernel':62s} {'calls':>6s} {'total_ms':>11s} {'avg_ms':>11s} {'min_ms':>11s} {'max_ms':>11s}")
     for r in rows:
         s = short(r["Name"])
@@ -68,13 +69,19 @@ for s, t in traffic.items():
     if "FETCH_SIZE" in t and "WRITE_SIZE" in t and key:
         wl, k = names[key]
         f, w = t["FETCH_SIZE"], t["WRITE_SIZE"]
+        # FETCH_SIZE x2 for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM); "other access widths are
+        # uncalibrated: calibrate on a known byte count in your own access pattern": the pack reads one 128-byte line per
+        # LANE (eight 16-byte loads of its own row), and against its known input (n x L bytes) the counter reads x1
+        fx = 1 if k == "pack_kernel" else 2
+        why = ("FETCH_SIZE x1: the pack's reads are one 128-byte line per lane, not a wave-wide coalesced stream — calibrated against "
+               "its known input (the n x L byte matrix), which the counter reports undoubled") if fx == 1 else \
+              ("FETCH_SIZE x2 (gfx950 16-B/lane streaming-read under-count; the consensus kernel's reads are mostly 8/16-byte gathers, "
+               "for which the x2 is an upper bound)")
         recs.append({"workload": wl, "kernel": k, "kernel_full": s, "FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0],
-                     "hbm_bytes_per_launch": f[0] * 1024 * 2 + w[0] * 1024,
-                     "hbm_bytes_min_max": [f[1] * 1024 * 2 + w[1] * 1024, f[2] * 1024 * 2 + w[2] * 1024],
+                     "hbm_bytes_per_launch": f[0] * 1024 * fx + w[0] * 1024,
+                     "hbm_bytes_min_max": [f[1] * 1024 * fx + w[1] * 1024, f[2] * 1024 * fx + w[2] * 1024],
                      "source": f"{os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, mean per launch "
-                               f"(min-max of the launches {(f[1]*2+w[1])*1024/1e9:.2f}-{(f[2]*2+w[2])*1024/1e9:.2f} GB); FETCH_SIZE x2 (gfx950 "
-                               "16-B/lane streaming-read under-count; the consensus kernel's reads are mostly 8/16-byte gathers, for which "
-                               "the x2 is an upper bound), KiB -> bytes"})
+                               f"(min-max of the launches {(f[1]*fx+w[1])*1024/1e9:.2f}-{(f[2]*fx+w[2])*1024/1e9:.2f} GB); {why}, KiB -> bytes"})
 json.dump(recs, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
