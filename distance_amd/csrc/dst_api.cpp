@@ -167,7 +167,7 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
             s.rec.pre_cold = s.rec.pre_hot = nullptr;
             s.rec.pre_totals = nullptr;
             s.rec.pre_cap = 0;
-            const size_t words = 5 * (n + 1) + 4 + ((2 * (n + 1)) & 1);   // totals on an 8-byte boundary
+            const size_t words = 5 * (n + 1) + 8 + ((2 * (n + 1)) & 1);   // four 64-bit totals on an 8-byte boundary
             HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, words * sizeof(uint32_t)));
             s.rec.pre_cap = n + 1;
         }
@@ -189,12 +189,12 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
             const size_t cap = s.rec.pre_cap, pad = (2 * cap) & 1;
             s.rec.pre_hot = s.rec.pre_cold + cap;
             s.rec.pre_totals = reinterpret_cast<unsigned long long *>(s.rec.pre_cold + 2 * cap + pad);
-            s.runs.cnt_run = s.rec.pre_cold + 2 * cap + pad + 4;
+            s.runs.cnt_run = s.rec.pre_cold + 2 * cap + pad + 8;
             s.runs.run_cold = s.runs.cnt_run + cap;
             s.runs.run_hot = s.runs.run_cold + cap;
             s.runs.ids = s.runs.index + s.runs.n_alloc;
             // (the pack's counts and first-invalid-byte cell are cleared on the sample's way: no fills of their own)
-            HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 5 * cap + pad + 4, d_first_bad));
+            HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 5 * cap + pad + 8, d_first_bad));
             HIP_TRY(ctx, launch_hot_list(s, stream));
         }
         pl.ref_planes = s.ref.planes;
@@ -258,7 +258,7 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     HIP_TRY(ctx, launch_report(ctx->d_first_bad,
                                want_lists ? reinterpret_cast<const unsigned long long *>(s.ref.stats) : nullptr,
                                want_lists ? s.rec.pre_cold : nullptr, want_lists ? s.rec.pre_hot : nullptr, n, ctx->d_report, stream,
-                               want_lists ? &s.runs : nullptr, max_run));
+                               want_lists ? &s.runs : nullptr, max_run, want_lists ? s.rec.pre_totals : nullptr));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     const unsigned long long first_bad = ctx->h_report[0], totals[2] = {ctx->h_report[9], ctx->h_report[10]};
     if (want_lists)

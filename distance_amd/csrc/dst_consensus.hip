@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ da
 // The same for up to kScanSmallMax elements in ONE launch (a 10,000-record step is a dozen short kernels: the three
 // launches of the general scan and the memset before it were 25 us of its 420): one block walks the array in pieces of
 // 4,096 with a running carry.  zero[0..n_zero) is cleared on the way (the counters the next kernels add to).
-constexpr size_t kScanSmallMax = 65536;
+constexpr size_t kScanSmallMax = 16384;   // (at 50,000 one block takes 36-49 us: more than the three launches it replaces)
 __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__ data, uint32_t n, const uint32_t *__restrict__ src0,
                                                           const uint32_t *__restrict__ src1, uint32_t *__restrict__ zero,
                                                           uint32_t n_zero)
@@ -807,23 +807,24 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__
     if (tid == 0)
         carry_s = 0;
     __syncthreads();
-    auto load4 = [&](uint32_t at, uint32_t (&v)[4]) {
+    constexpr int PER = 4;   // elements per thread and piece: 4,096 per round of the block
+    auto load_piece = [&](uint32_t at, uint32_t (&v)[PER]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < PER; ++k)
             v[k] = at + k < n ? (src0 ? src0[at + k] + (src1 ? src1[at + k] : 0u) : data[at + k]) : 0u;
     };
-    uint32_t nx[4];
-    load4(4 * tid, nx);
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t at = base + 4 * tid;
-        uint32_t v[4], sum = 0;
+    uint32_t nx[PER];
+    load_piece(PER * tid, nx);
+    for (uint32_t base = 0; base < n; base += PER * 1024) {
+        const uint32_t at = base + PER * tid;
+        uint32_t v[PER], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             v[k] = nx[k];
             sum += v[k];
         }
-        if (base + 4096 < n)
-            load4(at + 4096, nx);   // the next piece is on its way while this one is scanned
+        if (base + PER * 1024 < n)
+            load_piece(at + PER * 1024, nx);   // the next piece is on its way while this one is scanned
         uint32_t incl = sum, up;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__
         }
         uint32_t run = off + incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             if (at + k < n)
                 data[at + k] = run;
             run += v[k];
@@ -888,103 +889,81 @@ struct RunsArg {
     uint32_t max_run;   // more run records than this: stripping stays off (the correction tables would not pay / fit)
 };
 
+// The pack's list lengths summed by many blocks (one block took 45-60 us for 50,000 records: one CU's worth of memory
+// latency), on the way giving every record with fewer than kRunMin run chunks their entries back — those can never be run
+// records.  totals (zeroed): [0] cold entries, [1] hot entries, [2] candidates (records with >= kRunMin run chunks),
+// [3] the candidates' run-chunk entries.
+__global__ __launch_bounds__(256) void list_totals_kernel(uint32_t *__restrict__ cnt0, uint32_t *__restrict__ cnt1, uint32_t n,
+                                                          RunsArg runs, unsigned long long *__restrict__ totals)
+{
+    __shared__ unsigned long long part[4][4];
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t a = cnt0[i], b = cnt1[i];
+        const uint32_t chunks = runs.cnt_run ? runs.cnt_run[i] : 0u;
+        if (chunks) {
+            const uint32_t rc = runs.run_cold[i], rh = runs.run_hot[i];
+            if (chunks < kRunMin) {
+                if (rc)
+                    cnt0[i] = a += rc;
+                if (rh)
+                    cnt1[i] = b += rh;
+            } else {
+                v[2] += 1;
+                v[3] += rc + rh;
+            }
+        }
+        v[0] += a;
+        v[1] += b;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v[k] += __shfl_xor(v[k], o);
+        if ((threadIdx.x & 63u) == 0)
+            part[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t)
+            atomicAdd(&totals[threadIdx.x], t);
+    }
+}
+
+// What the host reads after an upload (one page-locked block, written by the device: no device-to-host copies), and the
+// decision about the run records: with candidates and room for their tables they are numbered in record order (1,024
+// records per round, a block scan of the flags); without room every candidate gets its entries back like the others.
 __global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *__restrict__ first_bad,
                                                       const unsigned long long *__restrict__ stats,
+                                                      const unsigned long long *__restrict__ totals,
                                                       uint32_t *__restrict__ cnt0, uint32_t *__restrict__ cnt1, uint32_t n,
                                                       unsigned long long *report, RunsArg runs)
 {
-    // the list totals: the pack's two count arrays summed here (a kernel of their own they were one more launch)
-    __shared__ unsigned long long part[16][4];
-    __shared__ uint32_t wave_tot[16], base_s, strip_s;
+    __shared__ uint32_t wave_tot[16], base_s;
+    __shared__ unsigned long long back[16][2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    auto block_sums = [&](unsigned long long (&v)[4]) {   // v[k] summed over the block, in every thread
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                v[k] += __shfl_xor(v[k], o);
-            if (lane == 0)
-                part[wv][k] = v[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = 0;
-            for (int w = 0; w < 16; ++w)
-                v[k] += part[w][k];
-        }
-        __syncthreads();
-    };
-    // pass 1: {cold entries, hot entries, run chunks, run records}
-    unsigned long long v[4] = {0, 0, 0, 0};
-    if (cnt0)
-        for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {   // many loads in flight per thread: one block, latency-bound
-            uint32_t a[8], b[8], r[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + 1024 * u;
-                a[u] = i < n ? cnt0[i] : 0u;
-                b[u] = i < n ? cnt1[i] : 0u;
-                r[u] = (runs.cnt_run && i < n) ? runs.cnt_run[i] : 0u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                v[0] += a[u];
-                v[1] += b[u];
-                v[2] += r[u];
-                v[3] += r[u] >= kRunMin ? 1u : 0u;
-            }
-        }
-    block_sums(v);
-    const bool any_run = v[2] != 0;
-    const bool strip = v[3] != 0 && v[3] <= runs.max_run;
-    if (any_run) {
-        // pass 2: the entries of run chunks go back into the list lengths of every record that keeps them; the run
-        // records get their numbers, in record order (1,024 records per round, a block scan of the flags)
+    unsigned long long cold = totals ? totals[0] : 0ull, hot = totals ? totals[1] : 0ull;
+    const unsigned long long cand = totals && runs.cnt_run ? totals[2] : 0ull, cand_entries = totals ? totals[3] : 0ull;
+    const bool strip = cand != 0 && cand <= runs.max_run;
+    if (cand != 0) {   // (uniform; rare: most alignments have no record with 512 sites of N in whole chunks)
         if (tid == 0)
             base_s = 0;
-        unsigned long long w2[4] = {0, 0, 0, 0};
+        unsigned long long gave[2] = {0, 0};
         __syncthreads();
-        if (!strip) {
-            // no run records (a few terminal gaps that fill a chunk: the usual case): every run chunk's entries go back,
-            // in any order — eight records per thread and round, their loads in flight together
-            for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
-                uint32_t ch[8];
-#pragma unroll
-                for (uint32_t u = 0; u < 8; ++u)
-                    ch[u] = i0 + 1024 * u < n ? runs.cnt_run[i0 + 1024 * u] : 0u;
-#pragma unroll
-                for (uint32_t u = 0; u < 8; ++u)
-                    if (ch[u]) {
-                        const uint32_t i = i0 + 1024 * u, rc = runs.run_cold[i], rh = runs.run_hot[i];
-                        if (rc)
-                            cnt0[i] += rc;
-                        if (rh)
-                            cnt1[i] += rh;
-                        w2[0] += rc;
-                        w2[1] += rh;
-                    }
-            }
-        }
-        for (uint32_t i0 = 0; strip && i0 < n; i0 += 1024) {
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
             const uint32_t i = i0 + tid;
-            const uint32_t chunks = i < n ? runs.cnt_run[i] : 0u;
-            const bool is_run = strip && chunks >= kRunMin;
-            if (chunks) {   // (most records have no run chunk at all: nothing to read, nothing to give back)
+            const bool is_cand = i < n && runs.cnt_run[i] >= kRunMin;
+            if (is_cand && !strip) {
                 const uint32_t rc = runs.run_cold[i], rh = runs.run_hot[i];
-                if (!is_run) {
-                    if (rc)
-                        cnt0[i] += rc;
-                    if (rh)
-                        cnt1[i] += rh;
-                    w2[0] += rc;
-                    w2[1] += rh;
-                } else {
-                    w2[2] += rc + rh;
-                }
+                cnt0[i] += rc;
+                cnt1[i] += rh;
+                gave[0] += rc;
+                gave[1] += rh;
             }
-            if (strip) {   // (uniform)
-                const unsigned long long m = __ballot(is_run);
+            if (strip) {
+                const unsigned long long m = __ballot(is_cand);
                 if (lane == 0)
                     wave_tot[wv] = (uint32_t)__builtin_popcountll(m);
                 __syncthreads();
@@ -995,8 +974,8 @@ __global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *
                 }
                 if (i < n) {
                     const uint32_t h = before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    runs.index[i] = is_run ? h : 0xFFFFFFFFu;
-                    if (is_run)
+                    runs.index[i] = is_cand ? h : 0xFFFFFFFFu;
+                    if (is_cand)
                         runs.ids[h] = i;
                 }
                 __syncthreads();
@@ -1005,30 +984,38 @@ __global__ __launch_bounds__(1024) void report_kernel(const unsigned long long *
                 __syncthreads();
             }
         }
-        block_sums(w2);
-        v[0] += w2[0];
-        v[1] += w2[1];
-        v[2] = w2[2];
-    } else {
-        v[2] = 0;
+        if (!strip) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    gave[k] += __shfl_xor(gave[k], o);
+                if (lane == 0)
+                    back[wv][k] = gave[k];
+            }
+            __syncthreads();
+            for (int w = 0; w < 16; ++w) {
+                cold += back[w][0];
+                hot += back[w][1];
+            }
+        }
     }
     if (runs.state && tid == 0) {
-        runs.state[0] = strip ? (uint32_t)v[3] : 0u;
+        runs.state[0] = strip ? (uint32_t)cand : 0u;
         runs.state[1] = strip ? 1u : 0u;
     }
-    (void)strip_s;
     if (tid == 0)
         report[0] = *first_bad;
     else if (tid <= 8)
         report[tid] = stats ? stats[tid - 1] : 0ull;
     else if (tid == 9)
-        report[9] = v[0];
+        report[9] = cold;
     else if (tid == 10)
-        report[10] = v[1];
+        report[10] = hot;
     else if (tid == 11)
-        report[11] = strip ? v[3] : 0ull;   // run records (0: the lists keep every entry)
+        report[11] = strip ? cand : 0ull;           // run records (0: the lists keep every entry)
     else if (tid == 12)
-        report[12] = strip ? v[2] : 0ull;   // entries their lists lost
+        report[12] = strip ? cand_entries : 0ull;   // entries their lists lost
 }
 
 // =============================================================================================
@@ -2370,12 +2357,17 @@ hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, uns
 
 hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, uint32_t *cnt_cold,
                          uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream, const RunIndex *runs,
-                         uint32_t max_run)
+                         uint32_t max_run, unsigned long long *totals)
 {
     RunsArg ra{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (runs && runs->cnt_run)
         ra = RunsArg{runs->cnt_run, runs->run_cold, runs->run_hot, runs->index, runs->ids, runs->state, max_run};
-    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(1024), 0, stream, first_bad, stats, cnt_cold, cnt_hot, (uint32_t)n, report, ra);
+    if (cnt_cold && totals) {   // (totals: four words the sample kernel cleared with the counters)
+        const unsigned blocks = (unsigned)std::min<size_t>(128, (n + 255) / 256);
+        hipLaunchKernelGGL(list_totals_kernel, dim3(blocks), dim3(256), 0, stream, cnt_cold, cnt_hot, (uint32_t)n, ra, totals);
+    }
+    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(1024), 0, stream, first_bad, stats, cnt_cold && totals ? totals : nullptr, cnt_cold,
+                       cnt_hot, (uint32_t)n, report, ra);
     return hipGetLastError();
 }
 

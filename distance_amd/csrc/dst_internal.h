@@ -296,9 +296,10 @@ constexpr int kReportWords = 13;   // [0] first invalid byte, [1..8] the sample'
 // counters — records with kRunMin run chunks and more become run records (numbered in runs->index / ids, word 11 = how
 // many; 0 when there are more than max_run: stripping off), every other record gets its run chunks' entries back into
 // its list length
+// totals: four zeroed 64-bit words (the set's pre_totals block: the sample kernel clears it with the counters)
 hipError_t launch_report(const unsigned long long *first_bad, const unsigned long long *stats, uint32_t *cnt_cold,
                          uint32_t *cnt_hot, size_t n, unsigned long long *report, hipStream_t stream, const RunIndex *runs = nullptr,
-                         uint32_t max_run = 0);
+                         uint32_t max_run = 0, unsigned long long *totals = nullptr);
 hipError_t launch_sum2_u32(const uint32_t *a0, const uint32_t *a1, size_t n, unsigned long long *totals, hipStream_t stream);
 // f_words: F_k (known reference sites x the per-site unit), packed like the accumulators
 hipError_t launch_consensus_pairs(int measure, const ConsensusLaunch &cl, const uint32_t f_words[kMaxWords],

@@ -88,7 +88,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
         s.rec.pre_cold = s.rec.pre_hot = nullptr;
         s.rec.pre_totals = nullptr;
         s.rec.pre_cap = 0;
-        const size_t words = 5 * (n + 1) + 4 + ((2 * (n + 1)) & 1);   // (pack_queue's layout: the run-chunk counters behind the totals)
+        const size_t words = 5 * (n + 1) + 8 + ((2 * (n + 1)) & 1);   // (pack_queue's layout: the run-chunk counters behind the totals)
         HIP_TRY(ctx, hipMalloc((void **)&s.rec.pre_cold, words * sizeof(uint32_t)));
         s.rec.pre_cap = n + 1;
     }
@@ -119,7 +119,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
         return rc;
     // ---- this rank's share: reference from the bytes, pack + count, scan, lists straight into the block
     // (the pack's counts and first-invalid-byte cell are cleared on the sample's way: no fills of their own)
-    HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 5 * s.rec.pre_cap + ((2 * s.rec.pre_cap) & 1) + 4,
+    HIP_TRY(ctx, launch_ref_sample_bytes(d_codes, row_stride, s, stream, s.rec.pre_cold, 5 * s.rec.pre_cap + ((2 * s.rec.pre_cap) & 1) + 8,
                                          ctx->d_first_bad));
     HIP_TRY(ctx, launch_hot_list(s, stream));
     PackLists pl{};
