@@ -607,7 +607,7 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
         // these lists' flavour (the hybrid path's lists leave the hot sites to the dense kernels)
         RunIndex &ru = s.runs;
         ru.mask_words = (s.nchunks + 31) / 32;
-        rc = ensure_bytes(ctx, (void **)&ru.mask, &ru.mask_cap, (size_t)ru.n_run * ru.mask_words * sizeof(uint32_t));
+        rc = ensure_bytes(ctx, (void **)&ru.mask, &ru.mask_cap, 2 * (size_t)ru.n_run * ru.mask_words * sizeof(uint32_t));   // by record, then transposed
         if (!rc)
             rc = ensure_bytes(ctx, (void **)&ru.known, &ru.known_cap, ((s.nchunks + 31) / 32 * 32) * sizeof(uint32_t));
         if (!rc)
@@ -656,7 +656,7 @@ int ensure_aconst(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, int family, boo
         if (!rc)
             rc = ensure_bytes(ctx, (void **)&ru.corr_t, &ru.corr_t_cap, words * ru.n_run * s.n * sizeof(uint32_t));
         if (!rc)   // the records' per-chunk sums in 7-bit pieces: the B operand of the correction tables' matrix product
-            rc = ensure_bytes(ctx, (void **)&ru.s7, &ru.s7_cap, words * 5 * s.n * 32 * ru.mask_words + 64);
+            rc = ensure_bytes(ctx, (void **)&ru.s7, &ru.s7_cap, words * 5 * ((s.n + 31) / 32) * 1024 * ru.mask_words + 64);   // whole tiles of 32 records
         if (rc)
             return rc;
     }

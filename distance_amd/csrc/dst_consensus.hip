@@ -1110,7 +1110,8 @@ __global__ __launch_bounds__(256) void run_known_kernel(const uint4 *__restrict_
 
 // the run chunks of every run record as a bit mask, from the flags the pack left in the slots
 __global__ __launch_bounds__(256) void run_masks_kernel(const uint4 *__restrict__ slots, const uint32_t *__restrict__ ids, uint32_t n_run,
-                                                        uint32_t nchunks, uint32_t npad, uint32_t mask_words, uint32_t *__restrict__ mask)
+                                                        uint32_t nchunks, uint32_t npad, uint32_t mask_words, uint32_t *__restrict__ mask,
+                                                        uint32_t *__restrict__ mask_t)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_run * mask_words)
@@ -1123,6 +1124,7 @@ __global__ __launch_bounds__(256) void run_masks_kernel(const uint4 *__restrict_
             m |= 1u << bit;
     }
     mask[i] = m;
+    mask_t[(size_t)k * n_run + h] = m;   // [word][run record]: what the table kernel's lanes read side by side
 }
 
 // first run record of every column panel: panel_first[p] = run records with id < p * kPanelCols (ids ascending)
@@ -1171,6 +1173,7 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const uint32_t *__restr
 {
     extern __shared__ uint32_t srow[];   // [4 waves][W][kpad]
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, r = blockIdx.x * 4u + wv;
+    const size_t n_tiles = (n + 31u) / 32u;
     uint32_t *mine = srow + (size_t)wv * W * kpad;
     for (uint32_t c = lane; c < W * kpad; c += 64)
         mine[c] = 0;
@@ -1202,7 +1205,11 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const uint32_t *__restr
                 const uint32_t sh = 7u * p;
                 const uint32_t packed = ((v[0] >> sh) & 127u) | ((v[1] >> sh) & 127u) << 8 | ((v[2] >> sh) & 127u) << 16 |
                                         ((v[3] >> sh) & 127u) << 24;
-                *reinterpret_cast<uint32_t *>(s7 + (((size_t)w * kSumPieces + p) * n + r) * kpad + c4) = packed;
+                // laid out as corr_mfma_kernel's lanes read it: per (tile of 32 records, step of 32 chunks) one contiguous KB,
+                // lane (half, record in tile) at 16 bytes x (32 half + record): a wave's operand load is eight whole lines
+                const size_t tile = r >> 5, ks = c4 >> 5, hf = (c4 >> 4) & 1u;
+                *reinterpret_cast<uint32_t *>(s7 + ((((size_t)w * kSumPieces + p) * n_tiles + tile) * (kpad / 32u) + ks) * 1024u +
+                                              (hf * 32u + (r & 31u)) * 16u + (c4 & 15u)) = packed;
             }
         }
     }
@@ -1229,7 +1236,7 @@ __device__ __forceinline__ v4i32_t spread16(uint32_t bits)
 // TRANSPOSED: the result goes to corr_t[w][record][run record] (through LDS: a row of 32 run records per record), else to
 // corr[w][run record][record] (32 consecutive records per lane group as the accumulators lie).
 template <int W, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void corr_mfma_kernel(const uint32_t *__restrict__ mask, uint32_t mask_words,
+__global__ __launch_bounds__(256) void corr_mfma_kernel(const uint32_t *__restrict__ mask_t, uint32_t mask_words,
                                                         const uint8_t *__restrict__ s7, uint32_t n, uint32_t n_run,
                                                         uint32_t *__restrict__ table)
 {
@@ -1240,16 +1247,17 @@ __global__ __launch_bounds__(256) void corr_mfma_kernel(const uint32_t *__restri
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, half = lane >> 5, idx = lane & 31u;
     const uint32_t r_col = blockIdx.x * 128u + wv * 32u + idx;     // this lane's record (B's column)
     const uint32_t h_base = blockIdx.y * (32u * kRunTiles);
-    const uint32_t kpad = 32u * mask_words;
     const bool b_live = r_col < n;
-    const uint32_t *mrow[kRunTiles];
+    // masks transposed ([k-step][run record]: 32 lanes read 128 contiguous bytes), sums tiled (see chunk_sums_kernel)
+    const uint32_t *mcol[kRunTiles];
     bool a_live[kRunTiles];
 #pragma unroll
     for (int t = 0; t < kRunTiles; ++t) {
         const uint32_t h_row = h_base + 32u * t + idx;             // this lane's run record of sub-tile t (A's row)
         a_live[t] = h_row < n_run;
-        mrow[t] = mask + (size_t)min(h_row, n_run - 1u) * mask_words;
+        mcol[t] = mask_t + min(h_row, n_run - 1u);
     }
+    const size_t n_tiles = (n + 31u) / 32u, r_tile = blockIdx.x * 4u + wv;
 #pragma unroll 1
     for (int w = 0; w < W; ++w) {
         uint32_t out[kRunTiles][16];
@@ -1260,48 +1268,45 @@ __global__ __launch_bounds__(256) void corr_mfma_kernel(const uint32_t *__restri
                 out[t][v] = 0;
 #pragma unroll 1
         for (int p = 0; p < kSumPieces; ++p) {
-            const uint8_t *brow = s7 + (((size_t)w * kSumPieces + p) * n + min(r_col, n - 1u)) * kpad + 16u * half;
+            const uint8_t *brow = s7 + (((size_t)w * kSumPieces + p) * n_tiles + min<size_t>(r_tile, n_tiles - 1)) * mask_words * 1024u +
+                                  lane * 16u;
             v16i32_t acc[kRunTiles];
 #pragma unroll
             for (int t = 0; t < kRunTiles; ++t)
                 acc[t] = v16i32_t{};
             // the operands of step ks + 1 are loaded before the MFMAs of step ks are issued: with four 16-register
             // accumulators a SIMD holds two or three of these waves, too few to hide a load per step behind each other
-            // (every load unconditional, from a clamped address, its value dropped by a select afterwards: written as
-            // conditional loads each became a branch with its own wait — five serial memory latencies per step)
-            auto load_step = [&](uint32_t ks, uint4 &bv, uint32_t (&bits)[kRunTiles]) {
-                const uint32_t kc = min(ks, mask_words - 1u);
-                const uint4 raw = *reinterpret_cast<const uint4 *>(brow + 32u * kc);
-                uint32_t word[kRunTiles];
+            // Eight k-steps (256 chunks) at a time, ALL their operands loaded before the first MFMA: a step is ~100 ns of
+            // issue and a load ~1.5 us away at two waves per SIMD, so operands fetched one step ahead (the first form of
+            // this loop) left the wave waiting for memory forty times per piece: 0.5 ms per table where the MFMAs are
+            // worth 0.05.  Every load is unconditional, from a clamped address, its value dropped by a select afterwards
+            // (written as conditional loads each became a branch with its own wait).
+            constexpr uint32_t KB = 8;
+            for (uint32_t k0 = 0; k0 < mask_words; k0 += KB) {
+                uint4 bv[KB];
+                uint32_t word[KB][kRunTiles];
 #pragma unroll
-                for (int t = 0; t < kRunTiles; ++t)
-                    word[t] = mrow[t][kc];
-                const bool on = ks < mask_words;
-                bv.x = (b_live && on) ? raw.x : 0u;
-                bv.y = (b_live && on) ? raw.y : 0u;
-                bv.z = (b_live && on) ? raw.z : 0u;
-                bv.w = (b_live && on) ? raw.w : 0u;
+                for (uint32_t j = 0; j < KB; ++j) {
+                    const uint32_t kc = min(k0 + j, mask_words - 1u);
+                    bv[j] = *reinterpret_cast<const uint4 *>(brow + 1024u * kc);
 #pragma unroll
-                for (int t = 0; t < kRunTiles; ++t)
-                    bits[t] = (a_live[t] && on) ? (word[t] >> (16u * half)) & 0xFFFFu : 0u;
-            };
-            // two operand sets in turn (no copies between them): the loads of one are in flight while the MFMAs of the other
-            // issue, and the wait in front of those MFMAs is for the OLDER loads only
-            auto mfma_step = [&](const uint4 &bv, const uint32_t (&bits)[kRunTiles]) {
-                v4i32_t bf;
-                bf.x = (int)bv.x, bf.y = (int)bv.y, bf.z = (int)bv.z, bf.w = (int)bv.w;
+                    for (int t = 0; t < kRunTiles; ++t)
+                        word[j][t] = mcol[t][(size_t)kc * n_run];
+                }
 #pragma unroll
-                for (int t = 0; t < kRunTiles; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(spread16(bits[t]), bf, acc[t], 0, 0, 0);
-            };
-            uint4 bv_a, bv_b;
-            uint32_t bits_a[kRunTiles], bits_b[kRunTiles];
-            load_step(0, bv_a, bits_a);
-            for (uint32_t ks = 0; ks < mask_words; ks += 2) {
-                load_step(ks + 1, bv_b, bits_b);
-                mfma_step(bv_a, bits_a);
-                load_step(ks + 2, bv_a, bits_a);
-                mfma_step(bv_b, bits_b);   // (past the last step: zeros)
+                for (uint32_t j = 0; j < KB; ++j) {
+                    const bool on = k0 + j < mask_words;
+                    v4i32_t bf;
+                    bf.x = (b_live && on) ? (int)bv[j].x : 0;
+                    bf.y = (b_live && on) ? (int)bv[j].y : 0;
+                    bf.z = (b_live && on) ? (int)bv[j].z : 0;
+                    bf.w = (b_live && on) ? (int)bv[j].w : 0;
+#pragma unroll
+                    for (int t = 0; t < kRunTiles; ++t) {
+                        const uint32_t bits = (a_live[t] && on) ? (word[j][t] >> (16u * half)) & 0xFFFFu : 0u;
+                        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(spread16(bits), bf, acc[t], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < kRunTiles; ++t)
@@ -2407,10 +2412,10 @@ hipError_t launch_run_tables(const DeviceSet &set, int family, bool wide, bool w
         /* the run COLUMNS' table from the plain sums, the run ROWS' table from the sums with the F terms folded in */              \
         hipLaunchKernelGGL((chunk_sums_kernel<WW>), dim3((n + 3) / 4), dim3(256), lds, stream, set.rec.off, set.rec.ent, ru.aent,     \
                            stride, n, kpad, ru.s7, nullptr, nullptr, nullptr, d_lut, family, wide ? 1 : 0);                           \
-        hipLaunchKernelGGL((corr_mfma_kernel<WW, true>), grid, dim3(256), 0, stream, ru.mask, mw, ru.s7, n, ru.n_run, ru.corr_t);     \
+        hipLaunchKernelGGL((corr_mfma_kernel<WW, true>), grid, dim3(256), 0, stream, ru.mask + (size_t)ru.n_run * mw, mw, ru.s7, n, ru.n_run, ru.corr_t);     \
         hipLaunchKernelGGL((chunk_sums_kernel<WW>), dim3((n + 3) / 4), dim3(256), lds, stream, set.rec.off, set.rec.ent, ru.aent,     \
                            stride, n, kpad, ru.s7, ru.index, ru.mask, ru.known, d_lut, family, wide ? 1 : 0);                         \
-        hipLaunchKernelGGL((corr_mfma_kernel<WW, false>), grid, dim3(256), 0, stream, ru.mask, mw, ru.s7, n, ru.n_run, ru.corr);      \
+        hipLaunchKernelGGL((corr_mfma_kernel<WW, false>), grid, dim3(256), 0, stream, ru.mask + (size_t)ru.n_run * mw, mw, ru.s7, n, ru.n_run, ru.corr);      \
     } while (0)
     switch (words) {
     case 1: DST_CORR(1); break;
@@ -2427,7 +2432,8 @@ hipError_t launch_run_masks(const DeviceSet &set, hipStream_t stream)
 {
     const uint32_t total = set.runs.n_run * (uint32_t)set.runs.mask_words;
     hipLaunchKernelGGL(run_masks_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, set.rec.pre_slots, set.runs.ids, set.runs.n_run,
-                       (uint32_t)set.nchunks, (uint32_t)set.npad, (uint32_t)set.runs.mask_words, set.runs.mask);
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, (uint32_t)set.runs.mask_words, set.runs.mask,
+                       set.runs.mask + (size_t)set.runs.n_run * set.runs.mask_words);
     return hipGetLastError();
 }
 

@@ -116,12 +116,13 @@ struct RunIndex {
     uint32_t *run_hot = nullptr;     // [n] ... at hot sites
     uint32_t *index = nullptr;       // [n] run record number of a record, or 0xFFFFFFFF
     uint32_t *ids = nullptr;         // [n] the run records, ascending
-    uint32_t *mask = nullptr;        // [n_run][mask_words] bit c: chunk c of the run record is a run chunk (from the slots' flags)
+    uint32_t *mask = nullptr;        // [n_run][mask_words] bit c: chunk c of the run record is a run chunk (from the slots' flags),
+                                     // then the same transposed, [mask_words][n_run]
     uint32_t *known = nullptr;       // [nchunks] known reference sites of every chunk (cold sites only: without_hot lists)
     uint32_t *panel_first = nullptr; // [n_panels + 1] first run record of every column panel
     uint32_t *state = nullptr;       // device: [0] run records, [1] 1: stripping is on for this upload
     uint32_t *aent = nullptr;        // [kMaxWords][entries] a-words of every list entry (aconst_kernel), what the tables sum
-    uint8_t *s7 = nullptr;           // [words][5][n][32 mask_words] every record's per-chunk sums of them, in 7-bit pieces
+    uint8_t *s7 = nullptr;           // [words][5][tiles of 32 records][mask_words][1 KB] every record's per-chunk sums of them, in 7-bit pieces
     uint32_t *corr = nullptr;        // [words][n_run][n]   X's terms by (run record, record) ...
     uint32_t *corr_t = nullptr;      // [words][n][n_run]   ... and transposed
     size_t n_alloc = 0, mask_words = 0, mask_cap = 0, known_cap = 0, panel_cap = 0, aent_cap = 0, corr_cap = 0, corr_t_cap = 0, s7_cap = 0;   // (capacities in bytes)
