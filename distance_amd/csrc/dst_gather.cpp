@@ -102,11 +102,11 @@ int comm_world(const dst_comm *c) { return c->world; }
 int comm_allgather(dst_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t stream)
 {
     dst_ctx *ctx = c->ctx;
-    if (c->world == 1) {
+    if (c->world == 1 && !c->comm && !c->custom) {
         if (d_recv != d_send)
             HIP_TRY(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, stream));
         return DST_OK;
-    }
+    }   // (a one-rank communicator with a transport still goes through it: the same call path as N ranks)
     if (c->custom) {
         const int rc = c->custom(c->custom_user, d_send, d_recv, bytes, (void *)stream);
         return rc == 0 ? DST_OK : fail(ctx, DST_ERR_HIP, "the communicator's all-gather callback failed");

@@ -56,7 +56,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     // shapes and settings the lists cannot serve (the same test on every rank): the replicated upload
-    const bool eligible = world > 1 && (ctx->path == DST_PATH_AUTO || ctx->path == DST_PATH_CONSENSUS) && n >= 2 && len > 0 &&
+    const bool eligible = (ctx->path == DST_PATH_AUTO || ctx->path == DST_PATH_CONSENSUS) && n >= 2 && len > 0 &&
                           n < kEntryMask && len < kSiteMask;
     if (!eligible)
         return pack_from_device(ctx, slot, d_codes, n, len, row_stride, nullptr, stream);

@@ -195,3 +195,24 @@ def test_text_of_a_shared_set_is_the_reference_text():
     for r0, r1, tl, text in ranks.run(body):
         host = oracle.finalize_square("tn93", tl, n, counts, r0, r1, threads=8)
         assert text == oracle.tsv_square("tn93", host, ids, r0, r1, threads=8)
+
+
+def test_one_rank_through_rccl_inside_the_library():
+    """The only RCCL a one-GPU box can run: a communicator of ONE rank (dst_comm_create -> ncclCommInitRank) and the shared
+    upload's ncclAllGather on it — the same calls, the same stream ordering as with N ranks, the exchange block coming back
+    through RCCL before it is spliced.  (N > 1 needs one GPU per rank: bench.py --gpus N on a multi-GPU node.)"""
+    n, L = 3_000, 4_000
+    codes = synth.alignment(synth.SEED ^ 9, n, L)
+    dcodes = torch.from_numpy(codes).cuda()
+    want = single_engine(codes, ("raw", "tn93"))
+    try:
+        uid = da.Comm.unique_id()
+    except da.DistanceError:
+        pytest.skip("librccl is not loadable on this box")
+    with da.Engine(0) as eng, da.Comm.rccl(eng, uid, 0, 1) as comm:
+        eng.upload_shared(comm, 0, dcodes.data_ptr(), n, L, dcodes.stride(0), with_counts=True)
+        st = eng.shared_stats()
+        assert st["shared_uploads"] == 1 and st["fallbacks"] == 0, st
+        for m in ("raw", "tn93"):
+            assert np.array_equal(eng.run_square(m), want[m], equal_nan=True), m
+        assert eng.last_path() == "consensus"
