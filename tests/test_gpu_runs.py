@@ -134,3 +134,46 @@ def test_two_files_after_a_square_run_and_the_text(eng):
     assert np.array_equal(eng.run_square("k80", 0, 40), sq, equal_nan=True)   # and the square job still answers the same
     eng.set_prep_threshold(2e10)
     eng.set_path("auto")
+
+
+def test_hot_columns_and_run_records_together(eng):
+    """clade-like columns (the hybrid path hands them to the dense kernels, the lists leave them out) AND records with runs of
+    N that cross them: F over a run chunk then counts the COLD known sites only, the dense part sees the N as they are"""
+    n, L = 1_800, 5_000
+    codes = with_runs(n, L, 51, 0.08, 0.4)
+    codes[: n // 3, ::40] = np.where(codes[: n // 3, ::40] >= 240, codes[: n // 3, ::40], 72)   # a third of the records share G there
+    rows = [0, 5, 7, n // 3 - 1, n // 3, n - 2]
+    want, want_t = dense_reference(codes, ALL, rows)
+    eng.set_prep_threshold(0)
+    for path in ("hybrid", "consensus", "auto"):
+        eng.set_path("auto")
+        eng.upload(0, codes)
+        eng.set_path(path)
+        for (m, r), w in want.items():
+            assert np.array_equal(eng.run_square(m, r, r + 1), w, equal_nan=True), (path, m, r)
+        for (m, r), w in want_t.items():
+            assert np.array_equal(eng.run_square(m, r, r + 1, tallies=True), w), (path, m, r)
+        if path == "hybrid":
+            assert eng.last_path() == "hybrid" and eng.run_records()[0] > 0
+    eng.set_prep_threshold(2e10)
+    eng.set_path("auto")
+
+
+def test_wide_alignment_one_word_per_tally(eng):
+    """L >= 65,536: 32-bit accumulators (up to four words per pair: the tables' matrix product per word), masks of 18 words
+    (three rounds of eight k-steps)"""
+    n, L = 420, 70_000
+    codes = with_runs(n, L, 53, 0.15, 0.5, extra=False)
+    rows = [0, 1, n // 2, n - 2]
+    want, want_t = dense_reference(codes, ALL, rows)
+    eng.set_prep_threshold(0)
+    eng.set_path("auto")
+    eng.upload(0, codes)
+    eng.set_path("consensus")
+    for (m, r), w in want.items():
+        assert np.array_equal(eng.run_square(m, r, r + 1), w, equal_nan=True), (m, r)
+    for (m, r), w in want_t.items():
+        assert np.array_equal(eng.run_square(m, r, r + 1, tallies=True), w), (m, r)
+    assert eng.run_records()[0] > 0
+    eng.set_prep_threshold(2e10)
+    eng.set_path("auto")
