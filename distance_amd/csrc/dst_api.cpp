@@ -110,6 +110,7 @@ int shape_set(dst_ctx *ctx, DeviceSet &s, size_t n, size_t len)
     s.loaded = false;
     s.have_counts = false;
     s.lean = false;
+    s.planes_deferred = false;
     s.partial = false;
     s.part_begin = s.part_end = 0;
     s.epoch += 1;  // new contents: the reference and the difference lists are rebuilt on demand
@@ -141,6 +142,12 @@ int alloc_ref(dst_ctx *ctx, DeviceSet &s)
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.partials, s.nchunks * 16 * sizeof(uint32_t)));
     s.ref.nchunks = s.nchunks;
     return DST_OK;
+}
+
+bool planes_deferred_by_pack()
+{
+    static const bool keep = std::getenv("DST_PACK_ALL_PLANES") != nullptr;   // measurement knob: the pack as it was before r03
+    return !keep;
 }
 
 // queue the pack of an n x len byte matrix (device memory) into `s`; *d_first_bad receives the first
@@ -204,6 +211,7 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         pl.cnt_cold = s.rec.pre_cold;
         pl.cnt_hot = s.rec.pre_hot;
         pl.slots = s.rec.pre_slots;
+        pl.defer_planes = planes_deferred_by_pack() ? 1 : 0;
         static const bool no_runs = std::getenv("DST_NO_RUN_RECORDS") != nullptr;   // measurement knob: r02's lists
         if (!no_runs) {
             pl.cnt_run = s.runs.cnt_run;
@@ -272,6 +280,7 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
         const double max_dev = kListsMaxDeviation * (double)len * (double)std::min<size_t>(n, kRefSamples);
         s.rec.pre_valid = (double)s.ref.h_stats[1] <= (double)(unsigned long long)max_dev;   // the kernel's own test
         s.lean = s.rec.pre_valid;   // ... which also made it skip the four derived planes
+        s.planes_deferred = s.rec.pre_valid && planes_deferred_by_pack();   // ... and the base planes of every inline chunk
         s.rec.pre_epoch = s.epoch;
         s.rec.pre_total_cold = totals[0];
         s.rec.pre_total_hot = totals[1];
@@ -283,15 +292,34 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     return DST_OK;
 }
 
+// Whatever reads a set's planes (the dense pair kernels, the hot columns' compaction, lists against another set's
+// reference, the consensus and differences calls) first has the base planes the pack deferred written, from the slots and
+// the reference they were taken against (planes_from_slots_kernel).  The consensus path never comes here.
+int ensure_planes(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
+{
+    if (!s.planes_deferred)
+        return DST_OK;
+    if (s.partial)
+        return fail(ctx, DST_ERR_STATE, "a set uploaded with dst_upload_shared runs on the consensus path only (its planes are "
+                                        "not stored)");
+    int rc = wait_for_other_runs(ctx, stream);
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, launch_planes_from_slots(s, stream));
+    s.planes_deferred = false;
+    return publish_prep(ctx, stream);
+}
+
 // the dense pair kernels read all eight planes: build the four derived ones of a set that was packed lean
 int ensure_derived(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
 {
     if (s.partial)
         return fail(ctx, DST_ERR_STATE, "a set uploaded with dst_upload_shared runs on the consensus path only (this rank holds "
                                         "the planes of its own records)");
-    if (!s.lean)
-        return DST_OK;
-    int rc = wait_for_other_runs(ctx, stream);
+    int rc = ensure_planes(ctx, s, stream);
+    if (rc || !s.lean)
+        return rc;
+    rc = wait_for_other_runs(ctx, stream);
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_derive(s, stream));
@@ -306,7 +334,15 @@ int need_counts(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     if (s.partial)
         return fail(ctx, DST_ERR_STATE, "the set was uploaded with dst_upload_shared without base counts (with_counts = 0): this rank "
                                         "holds the planes of its own records only");
-    HIP_TRY(ctx, launch_fill_counts(s, stream));
+    if (s.planes_deferred) {   // a chunk that is inline in its slot is counted from the slot
+        PackLists pl{};
+        pl.slots = s.rec.pre_slots;
+        pl.ref_planes = s.ref.planes;
+        pl.defer_planes = 1;
+        HIP_TRY(ctx, launch_fill_counts(s, stream, &pl));
+    } else {
+        HIP_TRY(ctx, launch_fill_counts(s, stream));
+    }
     // later runs may be queued on OTHER streams (multi-GPU sub-slabs alternate between two): they wait for this on
     // the device (order_after_prep)
     s.have_counts = true;
@@ -475,6 +511,8 @@ int ensure_ref(dst_ctx *ctx, DeviceSet &s, hipStream_t stream)
     int rc_alloc = alloc_ref(ctx, s);
     if (rc_alloc)
         return rc_alloc;
+    if (int rc_p = ensure_planes(ctx, s, stream))   // (the sample reads planes)
+        return rc_p;
     HIP_TRY(ctx, launch_ref_sample(s, stream));
     HIP_TRY(ctx, launch_hot_list(s, stream));
     HIP_TRY(ctx, hipMemcpyAsync(s.ref.h_stats, s.ref.stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
@@ -497,6 +535,9 @@ int ensure_hot(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, hipStream_t stream
     if (!s.hot)
         return DST_ERR_NOMEM;
     int rc = shape_set(ctx, *s.hot, s.n, n_hot);
+    if (rc)
+        return rc;
+    rc = ensure_planes(ctx, s, stream);   // (the hot columns are gathered from the planes)
     if (rc)
         return rc;
     HIP_TRY(ctx, launch_compact(s, refset.ref.hot_sites, (uint32_t)n_hot, *s.hot, stream));
@@ -561,8 +602,12 @@ int ensure_index(dst_ctx *ctx, DeviceSet &s, DeviceSet &refset, bool want_sites,
     unsigned long long total = 0;
     const uint32_t *scan_src0 = nullptr, *scan_src1 = nullptr;
     const bool from_pack = &s == &refset && s.rec.pre_valid && s.rec.pre_epoch == s.epoch;
-    if (!from_pack)
+    if (!from_pack) {
         s.runs.active = false;   // lists from the planes keep every entry (index_kernel knows no run chunks)
+        rc = ensure_planes(ctx, s, stream);
+        if (rc)
+            return rc;
+    }
     if (from_pack) {
         // the pack counted the list lengths against this very reference: no pass over the planes, no round trip
         // (the scan below reads the counts where the pack left them)
@@ -1233,6 +1278,14 @@ int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_
     return DST_OK;
 }
 
+int dst_planes_stored(const dst_ctx *ctx, int slot, int *stored)
+{
+    if (!ctx || slot < 0 || slot > 1 || !stored)
+        return DST_ERR_ARG;
+    *stored = ctx->set[slot].loaded && !ctx->set[slot].planes_deferred ? 1 : 0;
+    return DST_OK;
+}
+
 int dst_set_variant(dst_ctx *ctx, int variant)
 {
     if (!ctx || variant < 0)
@@ -1349,6 +1402,13 @@ int dst_consensus(dst_ctx *ctx, int both_slots, uint8_t *cons, size_t cap)
     const size_t bytes = a.len * 3 * sizeof(uint32_t);
     HIP_TRY(ctx, hipMalloc((void **)&d_hist, bytes));
     std::vector<uint32_t> hist(a.len * 3);
+    int rc_p = ensure_planes(ctx, a, ctx->stream);
+    if (!rc_p && two)
+        rc_p = ensure_planes(ctx, ctx->set[1], ctx->stream);
+    if (rc_p) {
+        (void)hipFree(d_hist);
+        return rc_p;
+    }
     hipError_t e = hipMemsetAsync(d_hist, 0, bytes, ctx->stream);
     if (e == hipSuccess)
         e = launch_site_hist(a, d_hist, ctx->stream);
@@ -1397,6 +1457,8 @@ int dst_differences(dst_ctx *ctx, int slot, const uint8_t *other, size_t len, ui
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_lut(ctx);
+    if (!rc)
+        rc = ensure_planes(ctx, s, ctx->stream);   // (the lists against `other` are taken from the planes)
     if (rc)
         return rc;
     // `other` as A, G, C, T planes (sites past len are N on both sides: never a difference)

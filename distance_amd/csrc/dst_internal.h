@@ -159,6 +159,9 @@ struct DeviceSet {
     size_t part_begin = 0, part_end = 0;
     bool lean = false;            // only the four base planes are stored (a low-diversity set headed for the consensus path):
                                   // the dense pair kernels' other planes are derived on demand (ensure_derived)
+    // the pack stored the base planes only of chunks that do not fit their slot (PackLists::defer_planes): the rest is the
+    // reference plus rec.pre_slots, written by ensure_planes the first time anything but the consensus path reads planes
+    bool planes_deferred = false;
     uint64_t epoch = 0;           // bumped by every upload: stale consensus indexes are rebuilt
     // consensus path
     ConsensusRef ref;
@@ -320,7 +323,11 @@ struct PackLists {
     uint4 *slots;                              // [nchunks][npad] the differences of every (record, chunk), see pack_kernel
     // run chunks (RunIndex; all NULL: not looked for): counted apart and flagged in the slot
     uint32_t *cnt_run, *run_cold, *run_hot;
+    // the base planes of a chunk that is inline in its slot are not stored (DeviceSet::planes_deferred)
+    int defer_planes;
 };
+// a slot that holds every difference of its (record, chunk): not a chunk of N (flag 0x100), at most kSlotEntries of them
+__host__ __device__ inline bool slot_is_inline(uint32_t word0) { return !(word0 & 0x100u) && (word0 & 0xFFu) <= kSlotEntries; }
 // rec_begin / rec_end: only those records are packed (one rank's share of a set: dst_upload_shared)
 hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSet &set,
                        unsigned long long *d_first_bad, const PackLists *lists, hipStream_t stream, size_t rec_begin = 0,
@@ -329,9 +336,15 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
 // byte, even site in the low nibble, a site = the high nibble of its Paradis code
 hipError_t launch_pack_nibbles(const uint8_t *d_nibbles, size_t row_stride, const DeviceSet &set, unsigned long long *d_first_bad,
                                hipStream_t stream);
-hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream);
+// lists: the pack's, when the set was packed with them (then a chunk that is inline in its slot is counted from the slot:
+// its planes may not be there)
+hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream, const PackLists *lists = nullptr);
 // the counts of records [rec_begin, rec_end) only, out[0..4) = record rec_begin's
-hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream);
+hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream,
+                               const PackLists *lists = nullptr);
+bool planes_deferred_by_pack();   // (false under DST_PACK_ALL_PLANES, the measurement knob)
+// the base planes the pack deferred, from the slots and the reference (DeviceSet::planes_deferred)
+hipError_t launch_planes_from_slots(const DeviceSet &set, hipStream_t stream);
 hipError_t launch_derive(const DeviceSet &set, hipStream_t stream);   // planes K, X1, X0, CL of a lean set from its base planes
 hipError_t launch_pairs(int measure, int variant, const PairLaunch &pl, hipStream_t stream);
 // close: the reference's operation order with the table logarithm (what the text path uses), not the epilogue's arithmetic

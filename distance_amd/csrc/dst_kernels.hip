@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
     // sequence (sampled from the bytes before this kernel).  Cold and hot sites apart: the hybrid path leaves the hot
     // ones out of the lists.  Skipped when the sample says the set is too diverse for lists.
     const bool low_diversity = lists.ref_planes && lists.stats[1] <= lists.max_dev_sum;
+    bool inline_slot = false;   // the slot says all there is to say about this chunk: its planes are not stored
     if (low_diversity) {
         uint32_t cold = 0, hot = 0;
         // ... and the entries themselves, while the codes are in registers: one 16-byte slot per (record, chunk) —
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
         // site-in-chunk | class of the reference << 7 | nibble << 10 | hot << 14.  The fill pass reads these slots
         // (1/4 of the planes it would read) and goes back to the planes only for a chunk with more differences.
         uint32_t slot[4] = {0, 0, 0, 0};
+        inline_slot = lists.defer_planes != 0;   // (a padding record: all N, nothing to keep)
         if (s < n) {
             const uint4 h4 = lists.hot_planes[c];
             const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w};
@@ -233,14 +235,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                 if (hot)
                     atomicAdd(&lists.cnt_hot[s], hot);
             }
+            inline_slot = inline_slot && slot_is_inline(slot[0]);
         }
         lists.slots[(size_t)c * npad + s] = make_uint4(slot[0], slot[1], slot[2], slot[3]);
     }
     // A set headed for the consensus path is stored lean: the K, X1, X0 and CL planes are functions of the four base
     // planes (derive_planes below) that only the dense pair kernels read; derive_kernel builds them if one ever runs.
+    // And its base planes are deferred (PackLists::defer_planes): the consensus path reads lists, not planes, and a chunk
+    // whose differences all sit in its slot is the reference plus those — planes_from_slots_kernel writes it if a dense
+    // kernel ever asks (half of this kernel's HBM traffic was these stores: 0.75 of 2.5 GB at 50,000 x 30,000).  Only a
+    // chunk that does not fit its slot (more than kSlotEntries differences, a chunk of N) is stored now: the fill pass
+    // reads those from the planes.
 #pragma unroll
     for (int p = 0; p < PL_COUNT; ++p)
-        if (p <= PL_T || !low_diversity)
+        if (p <= PL_T ? !inline_slot : !low_diversity)
             planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
 }
 
@@ -332,36 +340,123 @@ __global__ __launch_bounds__(256) void derive_kernel(uint4 *__restrict__ planes,
     planes[PL_CL * per_plane + i] = CL;
 }
 
-// {A,T,G,C} counts by code (src/fastaio.rs:53-66): a known base is K & its own bit-plane.
-__global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ planes,
-                                                     uint32_t nchunks, uint32_t npad,
+// The base planes of a set whose pack deferred them (DeviceSet::planes_deferred): one thread = one (record, chunk), as in
+// the pack.  A chunk that is inline in its slot is the reference's planes with the slot's entries written over them (an
+// entry = site in the chunk | ... | the record's four base bits << 10); the others the pack stored itself; padding
+// records are N.
+__global__ __launch_bounds__(256) void planes_from_slots_kernel(const uint4 *__restrict__ slots, const uint4 *__restrict__ ref_planes,
+                                                                uint32_t n, uint32_t nchunks, uint32_t npad,
+                                                                uint4 *__restrict__ planes)
+{
+    const uint32_t s = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (s >= npad)
+        return;
+    uint32_t out[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            out[p][w] = 0xFFFFFFFFu;   // all N
+    if (s < n) {
+        const uint4 slot = slots[(size_t)c * npad + s];
+        if (!slot_is_inline(slot.x))
+            return;
+        const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint4 r4 = ref_planes[(size_t)p * nchunks + c];
+            out[p][0] = r4.x; out[p][1] = r4.y; out[p][2] = r4.z; out[p][3] = r4.w;
+        }
+        const uint32_t cnt = slot.x & 0xFFu;
+#pragma unroll
+        for (uint32_t k = 1; k <= kSlotEntries; ++k) {
+            const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+            const uint32_t bit = k <= cnt ? 1u << (e & 31u) : 0u, word = (e >> 5) & 3u, nib = (e >> 10) & 15u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t m = word == (uint32_t)w ? bit : 0u;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)   // planes A, G, C, T = nibble bits 3, 2, 1, 0
+                    out[p][w] = (out[p][w] & ~m) | (((nib >> (3 - p)) & 1u) ? m : 0u);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        planes[((size_t)p * nchunks + c) * npad + s] = make_uint4(out[p][0], out[p][1], out[p][2], out[p][3]);
+}
+
+__device__ __forceinline__ void count_known(uint32_t A, uint32_t G, uint32_t C, uint32_t T, int &a, int &t, int &g, int &cc)
+{
+    const uint32_t K = (A ^ G ^ C ^ T) & ~((A & G) | (C & T));   // exactly one base (a lean set has no K plane)
+    a += __builtin_popcount(K & A);
+    t += __builtin_popcount(K & T);
+    g += __builtin_popcount(K & G);
+    cc += __builtin_popcount(K & C);
+}
+__device__ __forceinline__ void count_known4(const uint4 &A, const uint4 &G, const uint4 &C, const uint4 &T, int &a, int &t, int &g,
+                                             int &cc)
+{
+    count_known(A.x, G.x, C.x, T.x, a, t, g, cc);
+    count_known(A.y, G.y, C.y, T.y, a, t, g, cc);
+    count_known(A.z, G.z, C.z, T.z, a, t, g, cc);
+    count_known(A.w, G.w, C.w, T.w, a, t, g, cc);
+}
+
+// {A,T,G,C} counts by code (src/fastaio.rs:53-66): a known base is K & its own bit-plane.  A wave = 8 records x 8 chunk
+// lanes (128 contiguous bytes per chunk and plane).  With slots (a set packed with its lists): a chunk that is inline in
+// its slot has no planes yet — its counts are the reference's chunk, less the reference's base and plus the record's at
+// every entry of the slot (a quarter of the planes' bytes).
+__global__ __launch_bounds__(256) void counts_kernel(const uint4 *__restrict__ planes, const uint4 *__restrict__ slots,
+                                                     const uint4 *__restrict__ ref_planes,
+                                                     const unsigned long long *__restrict__ stats, unsigned long long max_dev_sum,
+                                                     uint32_t n, uint32_t nchunks, uint32_t npad,
                                                      uint32_t *__restrict__ counts, uint32_t rec_first, uint32_t rec_last)
 {
     // counts[0] is record rec_first's (the whole padded set, or one rank's share of it)
-    const uint32_t s = rec_first + blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= rec_last)
-        return;
-    uint32_t a = 0, t = 0, g = 0, cc = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t rl = lane & 7u, cl = lane >> 3;
+    const uint32_t s = rec_first + wave * 8u + rl;
+    const bool deferred = slots && (!stats || stats[1] <= max_dev_sum);   // (stats: the pack's own test, when the host has not seen it yet)
+    int a = 0, t = 0, g = 0, cc = 0;
     const size_t ps = (size_t)nchunks * npad;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const size_t at = (size_t)c * npad + s;
-        const uint4 A = planes[PL_A * ps + at], G = planes[PL_G * ps + at];
-        const uint4 C = planes[PL_C * ps + at], T = planes[PL_T * ps + at];
-        uint4 K;   // exactly one base: the K plane's bits, computed (a lean set has no K plane)
-        K.x = (A.x ^ G.x ^ C.x ^ T.x) & ~((A.x & G.x) | (C.x & T.x));
-        K.y = (A.y ^ G.y ^ C.y ^ T.y) & ~((A.y & G.y) | (C.y & T.y));
-        K.z = (A.z ^ G.z ^ C.z ^ T.z) & ~((A.z & G.z) | (C.z & T.z));
-        K.w = (A.w ^ G.w ^ C.w ^ T.w) & ~((A.w & G.w) | (C.w & T.w));
-        a += __builtin_popcount(K.x & A.x) + __builtin_popcount(K.y & A.y) +
-             __builtin_popcount(K.z & A.z) + __builtin_popcount(K.w & A.w);
-        t += __builtin_popcount(K.x & T.x) + __builtin_popcount(K.y & T.y) +
-             __builtin_popcount(K.z & T.z) + __builtin_popcount(K.w & T.w);
-        g += __builtin_popcount(K.x & G.x) + __builtin_popcount(K.y & G.y) +
-             __builtin_popcount(K.z & G.z) + __builtin_popcount(K.w & G.w);
-        cc += __builtin_popcount(K.x & C.x) + __builtin_popcount(K.y & C.y) +
-              __builtin_popcount(K.z & C.z) + __builtin_popcount(K.w & C.w);
+    if (s < rec_last && s < n) {
+        for (uint32_t c = cl; c < nchunks; c += 8u) {
+            const size_t at = (size_t)c * npad + s;
+            uint4 slot = make_uint4(0x100u, 0, 0, 0);
+            if (deferred)
+                slot = slots[at];
+            if (slot_is_inline(slot.x)) {
+                count_known4(ref_planes[c], ref_planes[nchunks + c], ref_planes[2 * (size_t)nchunks + c],
+                             ref_planes[3 * (size_t)nchunks + c], a, t, g, cc);
+                const uint32_t sw[4] = {slot.x, slot.y, slot.z, slot.w}, cnt = slot.x & 0xFFu;
+#pragma unroll
+                for (uint32_t k = 1; k <= kSlotEntries; ++k) {
+                    const uint32_t e = (sw[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    if (k <= cnt) {
+                        const uint32_t cls = (e >> 7) & 7u, nib = (e >> 10) & 15u;   // reference: 0 A, 1 G, 2 C, 3 T, 4 none
+                        a += (int)(nib == 8u) - (int)(cls == 0u);
+                        g += (int)(nib == 4u) - (int)(cls == 1u);
+                        cc += (int)(nib == 2u) - (int)(cls == 2u);
+                        t += (int)(nib == 1u) - (int)(cls == 3u);
+                    }
+                }
+            } else {
+                count_known4(planes[PL_A * ps + at], planes[PL_G * ps + at], planes[PL_C * ps + at], planes[PL_T * ps + at],
+                             a, t, g, cc);
+            }
+        }
     }
-    reinterpret_cast<uint4 *>(counts)[s - rec_first] = make_uint4(a, t, g, cc);
+#pragma unroll
+    for (uint32_t o = 8; o < 64u; o <<= 1) {
+        a += __shfl_xor(a, o);
+        t += __shfl_xor(t, o);
+        g += __shfl_xor(g, o);
+        cc += __shfl_xor(cc, o);
+    }
+    if (cl == 0 && s < rec_last)
+        reinterpret_cast<uint4 *>(counts)[s - rec_first] = make_uint4((uint32_t)a, (uint32_t)t, (uint32_t)g, (uint32_t)cc);
 }
 
 // =============================================================================================
@@ -752,7 +847,7 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
     const uint32_t last = (uint32_t)(rec_end >= set.n ? set.npad : rec_end);
     if (last <= first)
         return hipSuccess;
-    const PackLists none{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const PackLists none{};
     // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
                           (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);
@@ -779,20 +874,31 @@ hipError_t launch_derive(const DeviceSet &set, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream)
+hipError_t launch_planes_from_slots(const DeviceSet &set, hipStream_t stream)
 {
-    hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((set.npad + 255) / 256)), dim3(256), 0, stream,
-                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, set.counts, 0u, (uint32_t)set.npad);
+    dim3 grid((unsigned)set.nchunks, (unsigned)((set.npad + 255) / 256));
+    hipLaunchKernelGGL(planes_from_slots_kernel, grid, dim3(256), 0, stream, set.rec.pre_slots, set.ref.planes, (uint32_t)set.n,
+                       (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes);
     return hipGetLastError();
 }
 
-hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream)
+hipError_t launch_range_counts(const DeviceSet &set, size_t rec_begin, size_t rec_end, uint32_t *out, hipStream_t stream,
+                               const PackLists *lists)
 {
+    // (records past the set's own, the padding up to npad, count nothing)
     if (rec_end <= rec_begin)
         return hipSuccess;
-    hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((rec_end - rec_begin + 255) / 256)), dim3(256), 0, stream,
-                       set.planes, (uint32_t)set.nchunks, (uint32_t)set.npad, out, (uint32_t)rec_begin, (uint32_t)rec_end);
+    const bool slots = lists && lists->defer_planes;
+    hipLaunchKernelGGL(counts_kernel, dim3((unsigned)((rec_end - rec_begin + 31) / 32)), dim3(256), 0, stream, set.planes,
+                       slots ? lists->slots : nullptr, slots ? lists->ref_planes : nullptr, slots ? lists->stats : nullptr,
+                       slots ? lists->max_dev_sum : 0ull, (uint32_t)set.n, (uint32_t)set.nchunks, (uint32_t)set.npad, out,
+                       (uint32_t)rec_begin, (uint32_t)rec_end);
     return hipGetLastError();
+}
+
+hipError_t launch_fill_counts(const DeviceSet &set, hipStream_t stream, const PackLists *lists)
+{
+    return launch_range_counts(set, 0, set.npad, set.counts, stream, lists);
 }
 
 namespace {

@@ -130,6 +130,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     pl.cnt_cold = s.rec.pre_cold;
     pl.cnt_hot = s.rec.pre_hot;
     pl.slots = s.rec.pre_slots;
+    pl.defer_planes = planes_deferred_by_pack() ? 1 : 0;   // (a partial set runs on the consensus path only: nothing ever reads them)
     rc = timer_begin(ctx, 1, stream);
     if (rc)
         return rc;
@@ -143,7 +144,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     HIP_TRY(ctx, launch_slot_fill(s, s.ref.planes, s.ref.hot_planes, false, sh.off_local, block + lay.ent_at, nullptr, stream,
                                   rec_begin, rec_end, lay.ent_cap));
     if (with_counts)
-        HIP_TRY(ctx, launch_range_counts(s, rec_begin, rec_end, block + lay.counts_at, stream));
+        HIP_TRY(ctx, launch_range_counts(s, rec_begin, rec_end, block + lay.counts_at, stream, &pl));
     // ---- the exchange, and the lists of every record into the set's CSR
     rc = comm_allgather(comm, sh.send, sh.recv, block_bytes, stream);
     if (rc)
@@ -172,6 +173,7 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     s.part_begin = rec_begin;
     s.part_end = rec_end;
     s.lean = true;
+    s.planes_deferred = pl.defer_planes != 0;
     s.have_counts = with_counts != 0;
     s.ref.valid = true;
     s.rec.pre_valid = false;           // the slots cover this rank's records only

@@ -166,6 +166,12 @@ class Engine:
         self._check(self._lib.dst_run_records(self._h, slot, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def planes_stored(self, slot: int = 0) -> bool:
+        """False while the upload has deferred the set's bit-planes (a set prepared for the consensus path: dst_planes_stored)"""
+        v = C.c_int()
+        self._check(self._lib.dst_planes_stored(self._h, slot, C.byref(v)))
+        return bool(v.value)
+
     # ---- per-alignment precompute of -m n (src/lib.rs:223-231) ------------------------------
     def consensus(self, both_slots: bool = False) -> np.ndarray:
         """consensus() of src/fastaio.rs:289-336 over slot 0 (and slot 1), computed on the device."""

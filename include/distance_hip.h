@@ -128,6 +128,12 @@ int dst_set_path(dst_ctx *ctx, int path);
  * (DESIGN.md 3b'') — and how many list entries that removed.  0 when the set has none, too many (more than a third of the
  * records), or its lists were not built by the upload's fused preparation.  Diagnostic; the results do not depend on it. */
 int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_t *entries_removed);
+/* *stored = 1 when the bit-planes of every (record, 128-site chunk) of the set are in HBM; 0 while the upload has deferred them: a
+ * set prepared for the consensus path keeps, per chunk, its differences from the set's reference sequence (what that path
+ * reads), and the planes of a chunk are written only if it does not fit that form — the rest is written, from the
+ * reference and the differences, the first time something reads planes (a dense or hybrid run, dst_consensus,
+ * dst_differences, a run against another set).  Diagnostic; the results do not depend on it. */
+int dst_planes_stored(const dst_ctx *ctx, int slot, int *stored);
 /* DST_PATH_DENSE, DST_PATH_CONSENSUS or DST_PATH_HYBRID: what the most recent run on this context used */
 int dst_last_path(const dst_ctx *ctx);
 
