@@ -808,13 +808,19 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__
         carry_s = 0;
     __syncthreads();
     constexpr int PER = 4;   // elements per thread and piece: 4,096 per round of the block
-    auto load_piece = [&](uint32_t at, uint32_t (&v)[PER]) {
+    auto load_piece = [&](uint32_t at, uint32_t (&v)[PER]) {   // (n > 0; unconditional loads: a predicated one is a branch and a full wait)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = min(at + k, n - 1u);
+            v[k] = src0 ? src0[i] + (src1 ? src1[i] : 0u) : data[i];
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k)
-            v[k] = at + k < n ? (src0 ? src0[at + k] + (src1 ? src1[at + k] : 0u) : data[at + k]) : 0u;
+            v[k] = at + k < n ? v[k] : 0u;
     };
-    uint32_t nx[PER];
-    load_piece(PER * tid, nx);
+    uint32_t nx[PER] = {0, 0, 0, 0};
+    if (n)
+        load_piece(PER * tid, nx);
     for (uint32_t base = 0; base < n; base += PER * 1024) {
         const uint32_t at = base + PER * tid;
         uint32_t v[PER], sum = 0;
@@ -850,6 +856,72 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *__restrict__
         if (tid == 0)
             carry_s += total;
         __syncthreads();
+    }
+}
+
+// ... and up to kScanMidMax in one launch of several blocks without a word between them: block b scans elements
+// [4,096 b, 4,096 (b + 1)) and first sums everything in front of them itself (50,000 records: 13 blocks, 100 KB from L2 each
+// on average) — the general scan's three launches and their gaps were 25 us of a 2.8 ms step, 30 of the shared preparation's
+// 0.25 ms (it scans twice).
+constexpr size_t kScanMidMax = 262144;
+__global__ __launch_bounds__(1024) void scan_mid_kernel(uint32_t *__restrict__ data, uint32_t n, const uint32_t *__restrict__ src0,
+                                                        const uint32_t *__restrict__ src1, uint32_t *__restrict__ zero, uint32_t n_zero)
+{
+    __shared__ uint32_t wave_tot[16], wave_pre[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    constexpr uint32_t PER = 4, PIECE = PER * 1024;
+    if (blockIdx.x == 0 && tid < n_zero)
+        zero[tid] = 0;
+    auto value = [&](uint32_t i) { return src0[i] + (src1 ? src1[i] : 0u); };   // (never `data`: see below)
+    // this block's piece first (its loads are in flight while the prefix is summed) ...
+    const uint32_t at = blockIdx.x * PIECE + PER * tid;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k)
+        v[k] = value(min(at + k, n - 1u));   // (n > 0; unconditional loads, masked below)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        v[k] = at + k < n ? v[k] : 0u;
+        sum += v[k];
+    }
+    // ... then everything in front of it (in place, `data` in front of this piece may already hold another block's
+    // scan: the values come from src0 / src1 then, which no block writes; in place without src0 is not offered)
+    uint32_t pre = 0;
+    const uint32_t end = blockIdx.x * PIECE;
+    for (uint32_t i = tid; i < end; i += 16u * 1024u) {   // sixteen loads (of each array) in flight: this loop is latency
+        uint32_t t[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u)
+            t[u] = value(min(i + u * 1024u, end - 1u));   // (unconditional: a predicated load is a branch and a full wait)
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u)
+            pre += i + u * 1024u < end ? t[u] : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        pre += __shfl_xor(pre, o);
+    uint32_t incl = sum, up;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        up = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane == 63u)
+        wave_tot[wv] = incl;
+    if (lane == 0)
+        wave_pre[wv] = pre;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        off += wave_pre[w];
+        if (w < wv) off += wave_tot[w];
+    }
+    uint32_t run = off + incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        if (at + k < n)
+            data[at + k] = run;
+        run += v[k];
     }
 }
 
@@ -2149,24 +2221,37 @@ __global__ __launch_bounds__(256) void shared_entries_kernel(const uint32_t *__r
             rec_ent[base + i] = blk[lay.ent_at + i];
 }
 
-// where every record's list crosses each multiple of kBucketSites sites (what the fill passes note on their way)
+// where every record's list crosses each multiple of kBucketSites sites (what the fill passes note on their way): mark g
+// of a record = the index of its first entry at or beyond site g * kBucketSites.  One wave = one record, a lane = an
+// entry: it is the mark of every multiple that lies behind its predecessor's site and not behind its own.  (A binary
+// search per (record, multiple) — six dependent loads for each of 1.5 M threads — took 42 us at 50,000 x 30,000.)
 __global__ __launch_bounds__(256) void range_marks_kernel(const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_ent,
-                                                          uint32_t n, uint32_t npad, uint32_t *__restrict__ range_start,
-                                                          uint32_t ent_room)
+                                                          uint32_t n, uint32_t npad, uint32_t n_ranges,
+                                                          uint32_t *__restrict__ range_start, uint32_t ent_room)
 {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (r >= n)
         return;
-    uint32_t lo = min(rec_off[r], ent_room), hi = min(rec_off[r + 1], ent_room);
-    const uint32_t site = g * kBucketSites;
-    while (lo < hi) {   // first entry at or beyond `site`
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if ((rec_ent[mid] & kSiteMask) < site)
-            lo = mid + 1;
-        else
-            hi = mid;
+    const uint32_t lo = min(rec_off[r], ent_room), hi = min(rec_off[r + 1], ent_room);
+    uint32_t next = 0;   // marks [0, next) are written (the same in every lane)
+    for (uint32_t base = lo; base < hi; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool live = i < hi;
+        // the multiples up to this entry's site: g <= site / kBucketSites; the predecessor covered those up to its own
+        const uint32_t ent = rec_ent[min(i, hi - 1u)];   // (unconditional load)
+        const uint32_t mine = live ? min((ent & kSiteMask) / kBucketSites + 1u, n_ranges) : 0u;
+        uint32_t before = __shfl_up(mine, 1);
+        if (lane == 0)
+            before = next;
+        before = max(before, next);   // (sites ascend: `mine` does too)
+        if (live)
+            for (uint32_t g = before; g < mine; ++g)
+                range_start[(size_t)g * npad + r] = i;
+        const uint32_t last = min(hi - base, 64u) - 1u;
+        next = max(next, (uint32_t)__shfl(mine, last));
     }
-    range_start[(size_t)g * npad + r] = lo;
+    for (uint32_t g = next + lane; g < n_ranges; g += 64u)   // multiples behind the last entry
+        range_start[(size_t)g * npad + r] = hi;
 }
 
 // what the host reads after a shared upload: [0] first invalid byte over all ranks, [1..8] the sample's statistics,
@@ -2335,6 +2420,11 @@ hipError_t launch_exclusive_scan(uint32_t *data, size_t n, uint32_t *tmp, hipStr
         return hipSuccess;
     if (n <= kScanSmallMax) {
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, data, (uint32_t)n, src0, src1, zero, zero ? n_zero : 0u);
+        return hipGetLastError();
+    }
+    if (n <= kScanMidMax && src0 && data != src0 && data != src1 && (!zero || n_zero <= 1024)) {
+        hipLaunchKernelGGL(scan_mid_kernel, dim3((unsigned)((n + 4095) / 4096)), dim3(1024), 0, stream, data, (uint32_t)n, src0, src1,
+                           zero, zero ? n_zero : 0u);
         return hipGetLastError();
     }
     if (zero && n_zero) {
@@ -2548,7 +2638,7 @@ hipError_t launch_shared_splice(const uint32_t *gathered, const SharedLayout &la
     hipLaunchKernelGGL(shared_entries_kernel, dim3(std::max(1u, std::min(256u, lay.ent_cap / 1024u + 1u)), lay.world), dim3(256), 0,
                        stream, gathered, lay, n, set.rec.off, set.rec.ent, ent_room);
     const uint32_t n_ranges = (uint32_t)((set.nchunks * kChunkSites + kBucketSites - 1) / kBucketSites);
-    hipLaunchKernelGGL(range_marks_kernel, dim3((n + 255) / 256, n_ranges), dim3(256), 0, stream, set.rec.off, set.rec.ent, n, npad,
+    hipLaunchKernelGGL(range_marks_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, set.rec.off, set.rec.ent, n, npad, n_ranges,
                        set.rec.range_start, ent_room);
     hipLaunchKernelGGL(shared_report_kernel, dim3(1), dim3(64), 0, stream, gathered, lay,
                        reinterpret_cast<const unsigned long long *>(set.ref.stats), report);
