@@ -172,7 +172,12 @@ __global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const ui
             for (uint32_t u = 0; u < UNR; ++u) {
                 const uint32_t k = k0 + GROUPS * u;
                 const uint32_t r = sample_record(min(k, samples - 1), n, samples);
-                by[u] = site < len ? codes[(size_t)r * row_stride + site] : 0xF0u;
+                by[u] = codes[(size_t)r * row_stride + min(site, len - 1u)];   // (unconditional: all in flight together)
+            }
+            if (site >= len) {
+#pragma unroll
+                for (uint32_t u = 0; u < UNR; ++u)
+                    by[u] = 0xF0u;
             }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; ++u)
@@ -666,8 +671,8 @@ __global__ __launch_bounds__(kBucketThreads) void site_bucket_kernel(const uint3
             const uint32_t rr = tid + k * NT;
             uint32_t e[kBucketWalk];
 #pragma unroll
-            for (uint32_t j = 0; j < kBucketWalk; ++j)
-                e[j] = from[k] + j < to[k] ? rec_ent[from[k] + j] : 0u;
+            for (uint32_t j = 0; j < kBucketWalk; ++j)   // (unconditional loads from a clamped index: all in flight together)
+                e[j] = rec_ent[min(from[k] + j, to[k] ? to[k] - 1u : 0u)];
 #pragma unroll
             for (uint32_t j = 0; j < kBucketWalk; ++j)
                 if (from[k] + j < to[k])
@@ -1118,10 +1123,10 @@ __global__ __launch_bounds__(256) void aconst_kernel(const uint32_t *__restrict_
         uint32_t e[UNR];
 #pragma unroll
         for (uint32_t u = 0; u < UNR; ++u)
-            e[u] = i + 64 * u < end ? ent[i + 64 * u] : 0xFFFFFFFFu;
+            e[u] = ent[min(i + 64 * u, end - 1u)];   // (i < end; unconditional loads: all in flight together)
 #pragma unroll
         for (uint32_t u = 0; u < UNR; ++u) {
-            if (e[u] == 0xFFFFFFFFu)
+            if (i + 64 * u >= end)
                 continue;
             const uint32_t *a = lut->a[family][wide][(e[u] >> kSiteBits) & 7u][e[u] >> kEntryShift];
 #pragma unroll
@@ -1643,7 +1648,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
         rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
     if constexpr (ALIGNED)
         for (uint32_t k = threadIdx.x; k < kPanelCols; k += blockDim.x)
-            cola[k] = k < pcols ? col_a[panel0 + k] : 0u;
+            cola[k] = k < pcols ? col_a[panel0 + min(k, pcols - 1u)] : 0u;   // (the load itself unconditional: see HOIST below)
     if constexpr (LOGS)
         if (threadIdx.x < 128)
             logtab[threadIdx.x] = kLogTab[threadIdx.x];
@@ -1663,14 +1668,19 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
             for (int h = 0; h < 2; ++h) {
                 const uint32_t k = 2 * tid + 2 * OT * j + h;
                 const bool in = !event_role && k < pcols;
+                // (loads from a clamped column, masked afterwards: a predicated load compiles to a branch and a full
+                // wait, and these PAIRS x 2 x W loads of a tile's prologue then come one memory latency after another)
+                const uint32_t kc = min(k, pcols - 1u);
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    ca[j][h][w] = in ? col_a[(size_t)w * col_npad + panel0 + k] : 0u;
+                    const uint32_t av = col_a[(size_t)w * col_npad + panel0 + kc];
+                    ca[j][h][w] = in ? av : 0u;
                     // keep the VALUE in a register: left to itself hipcc re-loads it inside the output loop
                     asm volatile("" : "+v"(ca[j][h][w]));
                 }
                 if constexpr (HOIST_TC) {
-                    const uint4 t4 = in ? reinterpret_cast<const uint4 *>(t_counts)[panel0 + k] : make_uint4(0, 0, 0, 0);
+                    const uint4 tv = reinterpret_cast<const uint4 *>(t_counts)[panel0 + kc];
+                    const uint4 t4 = in ? tv : make_uint4(0, 0, 0, 0);
                     if constexpr (WIDE) {
                         tcp[j][h][0] = t4.x, tcp[j][h][1] = t4.y, tcp[j][h][2] = t4.z, tcp[j][h][3] = t4.w;
                     } else {
