@@ -252,26 +252,32 @@ __device__ __forceinline__ double fin_k80_fast(uint32_t count_L, uint32_t ts, ui
 __device__ __forceinline__ double fin_tn93_fast(uint32_t count_L, uint32_t count_d, uint32_t count_P1, uint32_t count_P2, uint4 qc,
                                                 uint4 tc, const LogEntry *tab)
 {
-    const uint64_t sA = (uint64_t)tc.x + qc.x, sT = (uint64_t)tc.y + qc.y, sG = (uint64_t)tc.z + qc.z, sC = (uint64_t)tc.w + qc.w;
-    // every product below needs its factors non-zero; counts of 2^24 and more (alignments beyond 16 M sites) go the long way
-    const bool plain = sA != 0 && sG != 0 && sT != 0 && sC != 0 && count_L != 0 && ((sA | sT | sG | sC | (uint64_t)count_L) >> 24) == 0;
-    if (!plain)
+    // Counts below 2^24 (alignments up to 16 M sites; larger ones go the long way): sums in 32 bits, one conversion
+    // instruction each, and every product below stays inside the f32 exponent range of rcp_fast's seed.  Every product also
+    // needs its factors non-zero.
+    const uint32_t sA = tc.x + qc.x, sT = tc.y + qc.y, sG = tc.z + qc.z, sC = tc.w + qc.w;
+    const uint32_t big = (qc.x | qc.y | qc.z | qc.w | tc.x | tc.y | tc.z | tc.w | count_L) >> 24;
+    const uint32_t least = min(min(min(sA, sG), min(sT, sC)), count_L);
+    if (big != 0 || least == 0)
         return fin_tn93_close(count_L, count_d, count_P1, count_P2, qc, tc, tab);
-    const double A = (double)sA, G = (double)sG, T = (double)sT, C = (double)sC;
-    const double R = (double)(sA + sG), Y = (double)(sT + sC), L = (double)(sA + sG + sT + sC);
-    const double AG = A * G, TC = T * C;
-    const double iR = rcp_fast(R), iY = rcp_fast(Y), iL = rcp_fast(L), icL = rcp_fast((double)count_L);
-    const double iAG = rcp_fast(AG), iTC = rcp_fast(TC);
+    const double A = (double)sA, G = (double)sG, T = (double)sT, C = (double)sC, cL = (double)count_L;
+    const double R = A + G, Y = T + C, L = R + Y;   // (integers below 2^26: exact)
+    const double AG = A * G, TC = T * C, RY = R * Y, AGTC = AG * TC;
+    // six reciprocals from two (each a quarter-rate f32 seed and a Newton step): 1 / (R Y L) < 2^-78 and
+    // 1 / (A G T C cL) < 2^-124 undone by the factors that are not wanted
+    const double i1 = rcp_fast(RY * L), i2 = rcp_fast(AGTC * cL);
+    const double iL = i1 * RY, iRY = i1 * L, iR = iRY * Y, iY = iRY * R;
+    const double icL = i2 * AGTC, iAGTC = i2 * cL, iAG = iAGTC * TC, iTC = iAGTC * AG;
     // P1 / k1 = P1 L R / (2 A G);  Q / (2 g_R) = Q L / (2 R);  Q / (2 g_R g_Y) = Q L^2 / (2 R Y)      (g_X = X / L)
     const double u = icL * L;
     const double hq = 0.5 * (double)(count_d - (count_P1 + count_P2)) * u;
     const double e1 = fma(hq, iR, 0.5 * ((double)count_P1 * u) * (R * iAG));
     const double e2 = fma(hq, iY, 0.5 * ((double)count_P2 * u) * (Y * iTC));
-    const double e3 = (hq * L) * (iR * iY);
+    const double e3 = (hq * L) * iRY;
     if (!(e1 < kSeriesMax && e2 < kSeriesMax && e3 < kSeriesMax))
         return fin_tn93_close(count_L, count_d, count_P1, count_P2, qc, tc, tab);
     const double k1 = 2.0 * AG * (iL * iR), k2 = 2.0 * TC * (iL * iY);
-    const double k3 = 2.0 * (iL * iL) * (R * Y - AG * (Y * iR) - TC * (R * iY));
+    const double k3 = 2.0 * (iL * iL) * (RY - AG * (Y * iR) - TC * (R * iY));
     double d = k1 * neg_ln1m(e1) + k2 * neg_ln1m(e2) + k3 * neg_ln1m(e3);
     if (d == 0.0)
         d = 0.0;
