@@ -284,11 +284,12 @@ def main():
                               "lists_and_constants": max(0.0, 1e3 * elapsed / steps - k_ms - float(np.mean(pack_ms)))}}
         leg["roofline"] = roofline(m, used, k_ms, total_pairs)
         # the whole step against the same roofline: what it must move through HBM at the least (the byte matrix read
-        # once, the bit-planes written once, the results written once) over the time of a step
-        step_bytes = n * L + n * ((L + 127) // 128) * 64 + total_pairs * 8
+        # once, the results written once) over the time of a step.  (r02 / early r03 also counted four base bit-planes
+        # written once; the default path no longer stores them: DESIGN.md 2.)
+        step_bytes = n * L + total_pairs * 8
         leg["whole_step"] = {"bound": "hbm", "achieved": step_bytes / (elapsed / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": step_bytes,
-                             "note": "byte matrix read once + four base bit-planes written once + 8 B per pair written once, "
+                             "note": "byte matrix read once + 8 B per pair written once, "
                                      "over the wall time of a step (pack, lists, tables, pair kernel, launch gaps and the upload's wait)"}
         return leg
 
