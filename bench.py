@@ -90,9 +90,12 @@ RAW_STEP_CEILING_NS = 10.6
 # consensus path: f64 VALU instructions of the fused finalisation per pair (ISA of consensus_pair_kernel: conversions,
 # the expanded division sequences, dst_log's polynomial), and the f64 vector peak in fma lanes per second
 F64_OPS_PER_PAIR = {"n": 0, "n_high": 0, "raw": 8, "jc69": 18, "k80": 33, "tn93": 117}   # tools/count_f64_ops.py (refreshed below)
+ALL_OPS_PER_PAIR = {}   # every instruction of the same finalisation (f64, conversions, integer, scalar)
 try:   # the committed count of the current epilogue (python tools/count_f64_ops.py > profiles/r03/f64_ops.json)
     with open(os.path.join(ROOT, "profiles", "r03", "f64_ops.json")) as _fh:
-        F64_OPS_PER_PAIR.update({m: rec["epilogue"]["f64"] for m, rec in json.load(_fh).items()})
+        _counts = json.load(_fh)
+    F64_OPS_PER_PAIR.update({m: rec["epilogue"]["f64"] for m, rec in _counts.items()})
+    ALL_OPS_PER_PAIR.update({m: rec["epilogue"]["all_instructions"] for m, rec in _counts.items()})
 except Exception:
     pass
 F64_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
@@ -372,12 +375,15 @@ def main():
                     "note": "f64 instructions of one finalisation in the kernel's ISA (tools/count_f64_ops.py) x pairs against the "
                             "f64 vector peak (78.6 TFLOP/s = 39.3e12 fma lanes/s); measured issue cost of one f64 op: "
                             "profiles/r02/ubench_f64_rate.txt"}
+            if m in ALL_OPS_PER_PAIR:   # ... and every instruction of it against one instruction per SIMD lane and clock
+                valu["all_instructions_per_pair"] = ALL_OPS_PER_PAIR[m]
+                valu["issue_frac"] = launch_pairs * ALL_OPS_PER_PAIR[m] / (k_ms * 1e-3) / F64_PEAK_LANE_OPS
             if valu["frac"] > hbm["frac"]:
                 r = valu
                 r["hbm"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
             else:
                 r = hbm
-                r["valu_f64"] = {k: valu[k] for k in ("achieved", "peak", "unit", "frac", "f64_ops_per_pair")}
+                r["valu_f64"] = {k: valu[k] for k in ("achieved", "peak", "unit", "frac", "f64_ops_per_pair", "issue_frac") if k in valu}
         tr = measured_traffic(args.workload if stock and m == measure else ("C3" if stock and args.workload == "C3raw" and m == "tn93" else ""), kernel)
         r["traffic"] = tr["hbm_bytes_per_launch"] if tr and world == 1 else None
         r["traffic_source"] = (tr["source"] + " — replayed from profiles/, not measured in this run") if tr and world == 1 else None
