@@ -14,7 +14,8 @@ src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 OURS = ("consensus_pair_kernel", "pair_kernel", "finalize_kernel", "pack_kernel", "counts_kernel", "index_kernel",
         "ref_sample_kernel", "hot_list_kernel", "site_bucket_kernel", "slot_fill_kernel", "derive_kernel", "sum2_u32_kernel", "add_u32_kernel", "aconst_kernel",
-        "scan_block_kernel", "scan_add_kernel", "scan_small_kernel", "compact_kernel", "report_kernel", "chunk_sums_kernel", "corr_mfma_kernel",
+        "scan_block_kernel", "scan_add_kernel", "scan_small_kernel", "scan_mid_kernel", "list_totals_kernel", "planes_from_slots_kernel",
+        "range_marks_kernel", "compact_kernel", "report_kernel", "chunk_sums_kernel", "corr_mfma_kernel",
         "run_masks_kernel", "run_known_kernel", "run_panels_kernel", "pack_nibbles_kernel", "number_kernel", "line_kernel")
 
 
