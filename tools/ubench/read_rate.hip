@@ -6,6 +6,7 @@
 //   r8c8     wave = 8 records x 8 chunks (a row's 1 KiB contiguous across 8 lanes), block = 32 records x 8 chunks
 //   r4c16    wave = 4 records x 16 chunks (2 KiB contiguous), block = 16 records x 16 chunks
 //   r1c64    wave = 1 record x 64 chunks (8 KiB contiguous), block = 4 records x 64 chunks
+//   rowstrU  wave = 1 record x 1 KiB per load instruction (a lane = 16 bytes), U such pieces per wave; results by record
 // Build: make -C tools/ubench read_rate ; run on the GPU box: tools/ubench/read_rate
 #include <hip/hip_runtime.h>
 
@@ -59,6 +60,35 @@ __global__ __launch_bounds__(256) void tile_kernel(const uint8_t *in, size_t str
     out[(size_t)c * npad + s] = fold(reinterpret_cast<const uint4 *>(in + (size_t)s * stride + (size_t)c * 128));
 }
 
+// a wave = one record x 1 KiB (eight chunks), a lane = 16 bytes: every load instruction covers whole lines; the eight
+// 16-byte results of the wave leave as one 128-byte store (results laid out by record: out[record][chunk])
+template <int UNROLL>
+__global__ __launch_bounds__(256) void rowstream_kernel(const uint8_t *in, size_t stride, uint32_t n, uint32_t nchunks, uint4 *out)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.y * 4u + wave;
+    if (s >= n)
+        return;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t g = blockIdx.x * UNROLL + u;      // group of eight chunks
+        if (g * 8u >= nchunks)
+            break;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g * 1024u + 16u * lane + 16u <= nchunks * 128u)
+            v = *reinterpret_cast<const uint4 *>(in + (size_t)s * stride + (size_t)g * 1024 + 16u * lane);
+        uint4 a = v;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            a.x ^= __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z ^= __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+        }
+        const uint4 mine = make_uint4(__shfl(a.x, (lane & 7u) * 8u), __shfl(a.y, (lane & 7u) * 8u), __shfl(a.z, (lane & 7u) * 8u),
+                                      __shfl(a.w, (lane & 7u) * 8u));
+        if (lane < 8u && g * 8u + lane < nchunks)
+            out[(size_t)s * nchunks + g * 8u + lane] = mine;
+    }
+}
+
 int main()
 {
     const uint32_t n = 50000, len = 30000, nchunks = len / 128, npad = 50048;   // 234 whole chunks
@@ -96,6 +126,19 @@ int main()
     CHECK(hipEventElapsedTime(&ms, e0, e1));                                                                                    \
     if (rep)                                                                                                                    \
         report(NAME, ms / 5);
+#define RUNS(NAME, U)                                                                                                           \
+    CHECK(hipEventRecord(e0));                                                                                                  \
+    for (int k = 0; k < 5; ++k)                                                                                                 \
+        hipLaunchKernelGGL((rowstream_kernel<U>), dim3((nchunks + 8 * U - 1) / (8 * U), (n + 3) / 4), dim3(256), 0, 0, in,          \
+                           (size_t)len, n, nchunks, out);                                                                       \
+    CHECK(hipEventRecord(e1));                                                                                                  \
+    CHECK(hipEventSynchronize(e1));                                                                                             \
+    CHECK(hipEventElapsedTime(&ms, e0, e1));                                                                                    \
+    if (rep)                                                                                                                    \
+        report(NAME, ms / 5);
+        RUNS("rowstr1", 1)
+        RUNS("rowstr4", 4)
+        RUNS("rowstr8", 8)
         RUN("lane_row", 64, 1)
         RUN("r8c8", 8, 8)
         RUN("r4c16", 4, 16)
