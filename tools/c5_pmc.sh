@@ -1,3 +1,4 @@
+# on the GPU box: C2 step timeline, then 200,000 x 1,000 jc69 / raw on the consensus path: default build, the -DDST_DBG_ALIGN_JC69 measurement build, PMC passes (profiles/r03/c5_jc69_pmc.txt)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03a; rm -rf $O; mkdir -p $O

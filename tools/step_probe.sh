@@ -1,3 +1,4 @@
+# on the GPU box: rocprofv3 kernel trace of bench.py at C2 and C3raw and one step of each as a timeline (gpurun_out/r03b/*_timeline.txt)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03b; rm -rf $O; mkdir -p $O
