@@ -261,8 +261,10 @@ int pack_from_device(dst_ctx *ctx, int slot, const uint8_t *d_codes, size_t n, s
     if (rc)
         return rc;
     // the device writes its report (first invalid byte, statistics, totals) into page-locked host memory: one wait
-    // run records (RunIndex): at most a third of the records, and correction tables (two, up to four words each) below 6 GB
-    const uint32_t max_run = (uint32_t)std::min<uint64_t>(n / 3, 6000000000ull / (32ull * std::max<size_t>(n, 1)));
+    // run records (RunIndex): at most a third of the records, and correction tables (two, up to four words each) below
+    // 24 GB of the 288 (6 GB until r03: 50,000 records of which a fifth carry runs of N lost their run records to it and
+    // took 35 ms where 20,000 such records took 1.7)
+    const uint32_t max_run = (uint32_t)std::min<uint64_t>(n / 3, 24000000000ull / (32ull * std::max<size_t>(n, 1)));
     HIP_TRY(ctx, launch_report(ctx->d_first_bad,
                                want_lists ? reinterpret_cast<const unsigned long long *>(s.ref.stats) : nullptr,
                                want_lists ? s.rec.pre_cold : nullptr, want_lists ? s.rec.pre_hot : nullptr, n, ctx->d_report, stream,
@@ -776,7 +778,7 @@ int cheapest_path(const DeviceSet &rows, const DeviceSet &cols, int measure, uin
         const double hot_dense = (double)pairs * (std::ceil(n_hot / 128.0) * 128.0 / dense_site_pairs_per_s[measure] + 2.2e-12);
         const double gather = (double)(rows.n + cols.n) * n_hot * 2.5e-11 + 1e-4;
         const double hybrid = (double)pairs * (out_s_per_pair[measure] + events_cold * event_s) + hot_dense + gather +
-                              ((have_lists && rows.rec.without_hot) ? 0.0 : build) + walk * mean_list_cold + 6e-5;
+                              ((have_lists && rows.rec.without_hot) ? 0.0 : build) + walk * mean_list_cold + 6e-5 + run_tables;
         if (hybrid < best) {
             best = hybrid;
             path = DST_PATH_HYBRID;

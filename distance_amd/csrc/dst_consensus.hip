@@ -1827,11 +1827,14 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 uint32_t col[UNR], v[UNR][W];
 #pragma unroll
                 for (uint32_t u = 0; u < UNR; ++u) {
-                    const uint32_t h = h0 + nt * u;
-                    col[u] = h < run_h1 ? rp.ids[h] - panel0 : 0xFFFFFFFFu;
+                    // (loads from a clamped index, masked afterwards: a predicated load is a branch and a full wait, and
+                    // the four would come one memory latency after another)
+                    const uint32_t h = h0 + nt * u, hc = min(h, run_h1 - 1u);
+                    const uint32_t id = rp.ids[hc];
+                    col[u] = h < run_h1 ? id - panel0 : 0xFFFFFFFFu;
 #pragma unroll
                     for (int w = 0; w < W; ++w)
-                        v[u][w] = h < run_h1 ? rp.corr_t[((size_t)w * rp.n + q) * rp.n_run + h] : 0u;
+                        v[u][w] = rp.corr_t[((size_t)w * rp.n + q) * rp.n_run + hc];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < UNR; ++u) {
@@ -1849,8 +1852,8 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
 #pragma unroll
                     for (uint32_t u = 0; u < UNR; ++u)
 #pragma unroll
-                        for (int w = 0; w < W; ++w)
-                            v[u][w] = k0 + nt * u < pcols ? rp.corr[((size_t)w * rp.n_run + hq) * rp.n + panel0 + k0 + nt * u] : 0u;
+                        for (int w = 0; w < W; ++w)   // (a clamped column: see above)
+                            v[u][w] = rp.corr[((size_t)w * rp.n_run + hq) * rp.n + panel0 + min(k0 + nt * u, pcols - 1u)];
 #pragma unroll
                     for (uint32_t u = 0; u < UNR; ++u) {
                         const uint32_t k = k0 + nt * u;

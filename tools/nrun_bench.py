@@ -64,5 +64,9 @@ for case in args.cases.split(","):
     a, d = res["auto"], res.get("dense", res["auto"])
     print(f"{share:5.2f} : {frac:4.2f}   auto -> {a[2]:9s} step {a[0]:8.3f} ms (pair kernel {a[1]:8.3f})   dense step {d[0]:8.3f} ms"
           f"   bits {'equal' if a[3] == d[3] else 'DIFFER'} {a[3]:016x}")
+    for other in res:
+        if other not in ("auto", "dense"):
+            o = res[other]
+            print(f"               {other:>9s} -> {o[2]:9s} step {o[0]:8.3f} ms (pair kernel {o[1]:8.3f})   bits {'equal' if o[3] == a[3] else 'DIFFER'}")
     del codes
 eng.close()
