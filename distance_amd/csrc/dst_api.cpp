@@ -980,7 +980,8 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             // (with any run records at all the four-wave variant is the faster one: 2.36 against 2.65 ms at 50,000 records
             // of which 1 % carry runs, 3.14 against 3.38 at 5 %: their adds come at the point of use, not through the
             // events' pipeline)
-            cl.heavy_events = events + run_adds > 1.0 ? 2 : events + run_adds > 0.3 || list > 100.0 || run_adds > 0.0 ? 1 : 0;
+            // ... and so do hybrid launches: the event waves also bring in the hot columns' tallies, a word per pair
+            cl.heavy_events = events + run_adds > 1.0 ? 2 : events + run_adds > 0.3 || list > 100.0 || run_adds > 0.0 || d_hot ? 1 : 0;
         }
         ctx->last_path = path;
         if (ntiles) {

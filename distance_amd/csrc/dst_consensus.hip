@@ -1879,6 +1879,44 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 }
         }
     };
+    // ---- hybrid path: the dense kernels' tallies of the hot columns (one packed word group per pair, canonical order) go
+    // into the accumulators like events, on the event side of the batch barrier.  Inside the output loop they were a global
+    // load between the result stores — gfx950 makes such a load wait for every store issued before it — and kept every
+    // group on do_pair's slow form: the pair kernel of a clade-structured 50,000 x 30,000 took 4.8 ms for 15 GB.
+    auto apply_hot = [&](uint32_t b, uint32_t t, uint32_t nt) {   // thread t of nt
+        if (!hot)
+            return;
+        const uint32_t q0 = tile.i0 + b * RB, nrows = min((uint32_t)RB, tile.i1 - q0);
+        uint32_t *bacc = acc + (UNI ? 0u : b & 1u) * ACC;
+        constexpr uint32_t UH = W == 1 ? 8 : 4;
+        for (uint32_t rb = 0; rb < nrows; ++rb) {
+            const uint32_t q = q0 + rb;
+            const uint64_t row_at = square ? (tri_row_start(n_cols, q) - out_base) - (uint64_t)(q + 1)
+                                           : (uint64_t)(q - row_begin) * n_cols;
+            uint32_t *racc = bacc + rb * W * kPanelCols;
+            const uint32_t kfirst = square && q + 1u > panel0 ? min(q + 1u - panel0, pcols) : 0u;   // columns past the diagonal
+            for (uint32_t k0 = kfirst + t; k0 < pcols; k0 += nt * UH) {
+                uint32_t v[UH][W];
+#pragma unroll
+                for (uint32_t u = 0; u < UH; ++u) {   // (clamped column, masked below: no predicated loads)
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        v[u][w] = 0;
+                    P::add_hot(v[u], hot, row_at + panel0 + min(k0 + nt * u, pcols - 1u));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UH; ++u) {
+                    const uint32_t k = k0 + nt * u;
+                    if (k >= pcols)
+                        continue;
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        if (v[u][w])
+                            atomicAdd(&racc[w * kPanelCols + k], v[u][w]);
+                }
+            }
+        }
+    };
     // ---- C of batch b from its accumulator buffer: constants, finalisation, canonical-order store
     auto output_batch = [&](const uint32_t b) {
         const uint32_t q0 = tile.i0 + b * RB;
@@ -1925,8 +1963,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                             cav = cav2[h][w];
                         tot[w] = a + cav + aq[w];
                     }
-                    if (hot && live[h])
-                        P::add_hot(tot, hot, at + h);   // hybrid path: the dense kernels' tallies of the hot columns
                     P::unpack(tot, o[h]);
                 }
                 if constexpr (OUT == OUT_INT) {
@@ -2023,7 +2059,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
             };
             // is the wave's group of 128 columns from k0 on (uniform) wholly inside the panel and past the diagonal?
             auto whole_group = [&](int32_t k0) {
-                return k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q) && hot == nullptr;
+                return k0 >= 0 && (uint32_t)k0 + 128u <= pcols && (!square || panel0 + (uint32_t)k0 > q);
             };
             if constexpr (ALIGNED) {
                 // The row's 2,048 results of this panel start `sh` elements into a 128-byte line.  The 16 (sh == 0)
@@ -2128,6 +2164,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
                 }
             }
             apply_runs(b, threadIdx.x, 64u * kBlockWaves);
+            apply_hot(b, threadIdx.x, 64u * kBlockWaves);
             DST_BATCH_BARRIER();
             output_batch(b);
             DST_BATCH_BARRIER();
@@ -2166,6 +2203,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
 #endif
                 }
                 apply_runs(step, tid, kEventLanes);
+                apply_hot(step, tid, kEventLanes);
                 // Rotate the pipeline FIRST — these copies read what the previous step's loads delivered, which has
                 // had a whole step to arrive — and only then issue the next loads.  Left to itself hipcc issues the
                 // loads first and copies at the end of the iteration, which needs s_waitcnt vmcnt(0) right behind the
