@@ -360,6 +360,8 @@ int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64
     for (auto &s : ctx->schedules) {
         if (s.square == square && s.rb == rb && s.re == re && s.ncols == ncols && s.bm == bm && s.bn == bn) {
             s.last_use = ++ctx->schedule_clock;
+            if (std::find(s.users.begin(), s.users.end(), stream) == s.users.end())
+                s.users.push_back(stream);
             *d_blocks = s.d_blocks;
             *nblocks = s.nblocks;
             return DST_OK;
@@ -390,14 +392,19 @@ int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64
     s.nblocks = (uint32_t)count;
     s.last_use = ++ctx->schedule_clock;
     if (ctx->schedules.size() >= kMaxSchedules) {
-        // evict the least recently used; a kernel queued on ANY stream may still read it (sub-slab launches alternate
-        // between streams, the caller may bring its own): wait for the device — evictions are rare, launches are not
-        (void)stream;
-        HIP_TRY(ctx, hipDeviceSynchronize());
+        // evict the least recently used; a kernel queued on any of the streams that launched with it may still read it
+        // (sub-slab launches alternate between streams, the caller may bring its own): those streams are waited for — not
+        // the device: a loop over row slabs (the CLI's text calls) evicts on every call.  A stream that is gone: the device.
         size_t victim = 0;
         for (size_t k = 1; k < ctx->schedules.size(); ++k)
             if (ctx->schedules[k].last_use < ctx->schedules[victim].last_use)
                 victim = k;
+        for (hipStream_t u : ctx->schedules[victim].users)
+            if (hipStreamSynchronize(u) != hipSuccess) {
+                (void)hipGetLastError();
+                HIP_TRY(ctx, hipDeviceSynchronize());
+                break;
+            }
         // its buffer is recycled when it is big enough (row slabs of one run have similar tile counts)
         void *spare = ctx->schedules[victim].d_blocks;
         const size_t spare_bytes = ctx->schedules[victim].bytes;
@@ -417,6 +424,7 @@ int prepare_schedule(dst_ctx *ctx, bool square, uint64_t rb, uint64_t re, uint64
         // pageable source: the copy is complete on return, later kernels on any stream see it
         HIP_TRY(ctx, hipMemcpy(s.d_blocks, src, bytes, hipMemcpyHostToDevice));
     }
+    s.users.assign(1, stream);
     ctx->schedules.push_back(s);
     *d_blocks = s.d_blocks;
     *nblocks = s.nblocks;

@@ -29,6 +29,7 @@ struct dst_ctx {
         void *d_blocks = nullptr;
         size_t bytes = 0;  // capacity of d_blocks
         uint64_t last_use = 0;
+        std::vector<hipStream_t> users;   // the streams whose launches read it (waited for before its buffer is recycled)
     };
     std::vector<Schedule> schedules;
     uint64_t schedule_clock = 0;
