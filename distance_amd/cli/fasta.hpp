@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <string>
 
 namespace cli {
@@ -112,18 +114,67 @@ private:
 // A block of whole records: uninitialised storage filled by fread (std::string::resize would zero it first).
 struct Block {
     std::unique_ptr<char[]> data;
+    const char *view = nullptr;   // the block's bytes when they are a piece of the mapped file (data is empty then)
     size_t len = 0, cap = 0;
+    const char *bytes() const { return view ? view : data.get(); }
 };
 
 // Cuts a stream into blocks of whole records so that blocks can be parsed in parallel: a block ends
 // just before a line that starts with '>' (every such line starts a record for bio's reader).  Each block is read
 // straight into its own buffer; only the partial record behind the last cut is copied (to the next block's front).
+// A regular file is mapped instead: its blocks are pieces of the mapping (no read into a buffer on the calling thread —
+// 1.5 GB of it were a third of the time a 50,000 x 30,000 load took —, the pages are touched by the threads that parse
+// them); same cuts.
 class BlockReader {
 public:
-    BlockReader(FILE *fh, size_t target_bytes) : fh_(fh), target_(target_bytes ? target_bytes : 1) {}
+    BlockReader(FILE *fh, size_t target_bytes) : fh_(fh), target_(target_bytes ? target_bytes : 1)
+    {
+        struct stat st;
+        const int fd = fileno(fh);
+        const off_t at = ftello(fh);
+        if (fd >= 0 && at >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                map_ = static_cast<const char *>(m);
+                map_len_ = (size_t)st.st_size;
+                pos_ = (size_t)at;
+                (void)madvise(m, map_len_, MADV_SEQUENTIAL);
+            }
+        }
+    }
+    ~BlockReader()
+    {
+        // (the mapping stays: blocks handed out may outlive the reader; the process unmaps it on exit)
+    }
     // false at end of input; otherwise `out` holds >= 1 whole record (the rest of the input at EOF)
     bool next(Block &out)
     {
+        if (map_) {
+            if (pos_ >= map_len_)
+                return false;
+            size_t end = std::min(map_len_, pos_ + target_), cut = 0;
+            for (;;) {
+                if (end == map_len_) {
+                    cut = map_len_;
+                    break;
+                }
+                // last "\n>" in [pos_, end): everything before the '>' is whole records
+                for (size_t p = end; p-- > pos_ + 1;)
+                    if (map_[p] == '>' && map_[p - 1] == '\n') {
+                        cut = p;
+                        break;
+                    }
+                if (cut > pos_)
+                    break;
+                end = std::min(map_len_, end + target_);   // one record longer than the target: look further
+            }
+            Block cur;
+            cur.view = map_ + pos_;
+            cur.len = cur.cap = cut - pos_;
+            pos_ = cut;
+            out = std::move(cur);
+            return true;
+        }
         Block cur;
         cur.cap = carry_.len + target_;
         cur.data.reset(new char[cur.cap]);
@@ -177,6 +228,8 @@ private:
     size_t target_;
     Block carry_;
     bool eof_ = false;
+    const char *map_ = nullptr;
+    size_t map_len_ = 0, pos_ = 0;
 };
 
 }  // namespace cli
