@@ -420,12 +420,18 @@ def main():
                               "tools/synth nrun_plan",
                               lambda t: synth.apply_nruns(t, synth.nrun_plan(args.seed ^ config_id, n, L))),
                 }
+                touched = {   # a record the variant changed (its row against the oracle below) and one it left alone
+                    "clades": [int(r) for r in synth.clade_plan(args.seed ^ config_id, n, L)[0][:1]],
+                    "nruns": [int(p[0]) for p in synth.nrun_plan(args.seed ^ config_id, n, L)[:1]],
+                }
                 for name, (what, apply) in variants.items():
                     var = apply(codes.clone())
                     torch.cuda.synchronize()
                     leg = single_gpu_leg(measure, args.path, full_out, data=var, steps=max(3, args.steps // 2))
                     leg["data"] = what
                     verify[name + "_vs_dense_bits_equal"] = bits_equal_dense(full_out, measure, var)
+                    verify["oracle_" + name] = oracle_rows(full_out, measure, var.cpu().numpy(),
+                                                           sorted({r for r in touched[name] + [1] if 0 <= r < n - 1}))
                     legs[name] = leg
                     del var
             eng.set_path(args.path)
