@@ -985,11 +985,16 @@ int run_sets(dst_ctx *ctx, int measure, bool square, DeviceSet &rows, DeviceSet 
             const double events = f * f * (double)(hybrid ? st[7] : st[2]) / (S * S), list = f * (double)(hybrid ? st[6] : st[1]) / S;
             // (a run record's row or column adds one word per pair from the correction tables: like an event, a cheaper one)
             const double run_adds = cols.runs.active && square ? 2.0 * cols.runs.n_run / std::max<double>((double)cols.n, 1.0) : 0.0;
-            // (with any run records at all the four-wave variant is the faster one: 2.36 against 2.65 ms at 50,000 records
-            // of which 1 % carry runs, 3.14 against 3.38 at 5 %: their adds come at the point of use, not through the
-            // events' pipeline)
-            // ... and so do hybrid launches: the event waves also bring in the hot columns' tallies, a word per pair
-            cl.heavy_events = events + run_adds > 1.0 ? 2 : events + run_adds > 0.3 || list > 100.0 || run_adds > 0.0 || d_hot ? 1 : 0;
+            // The 4 + 4 wave split beyond event-heavy launches (raw at 50,000 x 30,000 unless noted): any run records at all
+            // (1 % of the records: 2.36 against 2.65 ms, 5 %: 3.14 against 3.38 — their adds come at the point of use, not
+            // through the events' pipeline); hybrid launches (the event waves also bring in the hot columns' tallies, a
+            // word per pair); launches of a few rounds of workgroups (10,000 records: raw 0.121 -> 0.117 ms, n_high 0.111 ->
+            // 0.108, k80 0.199 -> 0.193; even at 20,000, 0.4 % slower at 30,000: with little to overlap it with, a tile's
+            // first events are what a workgroup waits for).  Not tn93, whose eight waves all take both roles
+            // (event_waves()), and not jc69 (0.128 -> 0.154 ms at 10,000 records: its f64 output wants the six waves).
+            const bool split_helps = measure != DST_TN93 && measure != DST_JC69 &&
+                                     (run_adds > 0.0 || d_hot || total_pairs < 120000000ull);
+            cl.heavy_events = events + run_adds > 1.0 ? 2 : events + run_adds > 0.3 || list > 100.0 || split_helps ? 1 : 0;
         }
         ctx->last_path = path;
         if (ntiles) {
