@@ -177,3 +177,31 @@ def test_wide_alignment_one_word_per_tally(eng):
     assert eng.run_records()[0] > 0
     eng.set_prep_threshold(2e10)
     eng.set_path("auto")
+
+
+def test_a_fifth_of_fifty_thousand_records_with_runs_keep_their_run_records():
+    """50,000 records of which a fifth carry runs of N: 10,000 run records, whose correction tables (two x n_run x n words)
+    the r03 budget (24 GB) holds — at 6 GB they fell back to whole lists and took 35 ms where 20,000 such records took 1.7.
+    Rows of run records and of others against the dense kernels' bits and the oracle."""
+    n, L = 50_000, 4_096
+    codes = synth.alignment(synth.SEED ^ 43, n, L)
+    plan = synth.nrun_plan(43, n, L, 0.2, 0.25)
+    synth.apply_nruns(codes, plan)
+    run_rows = sorted({r for r, _, _ in plan})
+    rows = sorted({0, run_rows[0], run_rows[len(run_rows) // 2], run_rows[-1], n // 3, n - 2} - {n - 1})
+    want, _ = dense_reference(codes, ("raw", "tn93"), rows)
+    with da.Engine(0) as eng:
+        eng.set_prep_threshold(0)
+        eng.set_path("consensus")
+        eng.upload(0, codes)
+        for m in ("raw", "tn93"):
+            for r in rows:
+                assert np.array_equal(eng.run_square(m, r, r + 1), want[(m, r)], equal_nan=True), (m, r)
+        n_run, removed = eng.run_records(0)
+        assert n_run > 5_000 and removed > 0, (n_run, removed)    # (more than the 3,750 a 6 GB budget allowed)
+        rng = np.random.default_rng(3)
+        for i in (run_rows[0], n // 3):
+            for j in rng.integers(i + 1, n, 6):
+                j = int(j)
+                got = eng.run_square("raw", i, i + 1)[j - i - 1]
+                assert got == oracle.pair_distance("raw", codes[i], codes[j]) or (np.isnan(got) and np.isnan(oracle.pair_distance("raw", codes[i], codes[j])))
