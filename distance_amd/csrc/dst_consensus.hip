@@ -1647,8 +1647,10 @@ __global__ __launch_bounds__(64 * kBlockWaves, OUT == DST_TN93 ? 4 : 2) void con
     if (threadIdx.x <= trows)
         rofs[threadIdx.x] = row_off[tile.i0 + threadIdx.x];
     if constexpr (ALIGNED)
-        for (uint32_t k = threadIdx.x; k < kPanelCols; k += blockDim.x)
-            cola[k] = k < pcols ? col_a[panel0 + min(k, pcols - 1u)] : 0u;   // (the load itself unconditional: see HOIST below)
+        for (uint32_t k = threadIdx.x; k < kPanelCols; k += blockDim.x) {
+            const uint32_t av = col_a[panel0 + min(k, pcols - 1u)];   // (unconditional, masked: see HOIST below)
+            cola[k] = k < pcols ? av : 0u;
+        }
     if constexpr (LOGS)
         if (threadIdx.x < 128)
             logtab[threadIdx.x] = kLogTab[threadIdx.x];
