@@ -60,6 +60,24 @@ __global__ __launch_bounds__(256) void tile_kernel(const uint8_t *in, size_t str
     out[(size_t)c * npad + s] = fold(reinterpret_cast<const uint4 *>(in + (size_t)s * stride + (size_t)c * 128));
 }
 
+// lane = record as in lane_row, but a thread takes K consecutive chunks of its record one after the other: a block reads
+// 256 records x K x 128 contiguous bytes of each
+template <int K>
+__global__ __launch_bounds__(256) void lane_rowk_kernel(const uint8_t *in, size_t stride, uint32_t n, uint32_t nchunks, uint32_t npad,
+                                                        uint4 *out)
+{
+    const uint32_t s = blockIdx.y * 256u + threadIdx.x;
+    if (s >= n)
+        return;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const uint32_t c = blockIdx.x * K + k;
+        if (c >= nchunks)
+            break;
+        out[(size_t)c * npad + s] = fold(reinterpret_cast<const uint4 *>(in + (size_t)s * stride + (size_t)c * 128));
+    }
+}
+
 // a wave = one record x 1 KiB (eight chunks), a lane = 16 bytes: every load instruction covers whole lines; the eight
 // 16-byte results of the wave leave as one 128-byte store (results laid out by record: out[record][chunk])
 template <int UNROLL>
@@ -136,6 +154,19 @@ int main()
     CHECK(hipEventElapsedTime(&ms, e0, e1));                                                                                    \
     if (rep)                                                                                                                    \
         report(NAME, ms / 5);
+#define RUNK(NAME, K)                                                                                                           \
+    CHECK(hipEventRecord(e0));                                                                                                  \
+    for (int k = 0; k < 5; ++k)                                                                                                 \
+        hipLaunchKernelGGL((lane_rowk_kernel<K>), dim3((nchunks + K - 1) / K, (n + 255) / 256), dim3(256), 0, 0, in, (size_t)len, n, \
+                           nchunks, npad, out);                                                                                 \
+    CHECK(hipEventRecord(e1));                                                                                                  \
+    CHECK(hipEventSynchronize(e1));                                                                                             \
+    CHECK(hipEventElapsedTime(&ms, e0, e1));                                                                                    \
+    if (rep)                                                                                                                    \
+        report(NAME, ms / 5);
+        RUNK("lanerow2", 2)
+        RUNK("lanerow4", 4)
+        RUNK("lanerow8", 8)
         RUNS("rowstr1", 1)
         RUNS("rowstr4", 4)
         RUNS("rowstr8", 8)
