@@ -52,7 +52,6 @@ _SIGS = {
     "dst_last_path": (C.c_int, [_vp]),
     "dst_run_records": (C.c_int, [_vp, C.c_int, _u64p, _u64p]),
     "dst_planes_stored": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
-    "dst_set_pack_staged": (C.c_int, [_vp, C.c_double]),
     "dst_consensus": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "dst_differences": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _u64p]),
     "dst_site_tallies": (C.c_int, [C.c_int, C.c_uint8, C.c_uint8, C.POINTER(C.c_int)]),

@@ -68,7 +68,7 @@ int ensure_bytes(dst_ctx *ctx, void **ptr, size_t *have, size_t want)
 
 void free_set(DeviceSet &s)
 {
-    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.codes, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.range_start, s.rec.pre_cold, s.rec.pre_slots,
+    void *bufs[] = {s.planes, s.counts, s.ref.planes, s.ref.hot_planes, s.ref.hot_sites, s.ref.stats, s.ref.partials, s.rec.off, s.rec.ent, s.rec.range_start, s.rec.pre_cold, s.rec.pre_slots,
                     s.site.inl, s.site.ent, s.aconst, s.runs.index, s.runs.mask, s.runs.known, s.runs.panel_first, s.runs.state,
                     s.runs.aent, s.runs.corr, s.runs.corr_t, s.runs.s7};   // (runs.cnt_run / run_cold / run_hot / ids live in the pre_cold and index blocks)
     for (void *b : bufs)
@@ -127,19 +127,17 @@ int alloc_ref(dst_ctx *ctx, DeviceSet &s)
 {
     if (s.ref.nchunks == s.nchunks && s.ref.planes)
         return DST_OK;
-    for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats, (void *)s.ref.partials, (void *)s.ref.codes})
+    for (void *b : {(void *)s.ref.planes, (void *)s.ref.hot_planes, (void *)s.ref.hot_sites, (void *)s.ref.stats, (void *)s.ref.partials})
         if (b)
             HIP_TRY(ctx, hipFree(b));
     s.ref.planes = nullptr;
     s.ref.hot_planes = nullptr;
     s.ref.hot_sites = nullptr;
-    s.ref.codes = nullptr;
     s.ref.stats = nullptr;
     s.ref.partials = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.planes, 4 * s.nchunks * sizeof(uint4)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_planes, s.nchunks * sizeof(uint4)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.hot_sites, s.nchunks * kChunkSites * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&s.ref.codes, s.nchunks * kChunkSites));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.stats, 8 * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc((void **)&s.ref.partials, s.nchunks * 16 * sizeof(uint32_t)));
     s.ref.nchunks = s.nchunks;
@@ -214,7 +212,6 @@ int pack_queue(dst_ctx *ctx, DeviceSet &s, const uint8_t *d_codes, size_t n, siz
         pl.cnt_hot = s.rec.pre_hot;
         pl.slots = s.rec.pre_slots;
         pl.defer_planes = planes_deferred_by_pack() ? 1 : 0;
-        pl.ref_codes = pl.defer_planes && (double)n * (double)len >= ctx->pack_staged_min_bytes ? s.ref.codes : nullptr;
         static const bool no_runs = std::getenv("DST_NO_RUN_RECORDS") != nullptr;   // measurement knob: r02's lists
         if (!no_runs) {
             pl.cnt_run = s.runs.cnt_run;
@@ -1297,14 +1294,6 @@ int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_
         *run_records = s.runs.active ? s.runs.n_run : 0;
     if (entries_removed)
         *entries_removed = s.runs.active ? s.runs.removed : 0;
-    return DST_OK;
-}
-
-int dst_set_pack_staged(dst_ctx *ctx, double min_bytes)
-{
-    if (!ctx || !(min_bytes >= 0.0))
-        return DST_ERR_ARG;
-    ctx->pack_staged_min_bytes = min_bytes;
     return DST_OK;
 }
 

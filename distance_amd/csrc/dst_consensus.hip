@@ -145,7 +145,7 @@ __global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const ui
                                                          uint4 *__restrict__ hot_planes,
                                                          uint32_t *__restrict__ partials,
                                                          uint32_t *__restrict__ zero, uint32_t zero_words,
-                                                         unsigned long long *__restrict__ first_bad, uint8_t *__restrict__ ref_codes)
+                                                         unsigned long long *__restrict__ first_bad)
 {
     // what the pack behind this kernel adds to / takes the minimum of, cleared here instead of by two fills of their own
     if constexpr (BYTES) {
@@ -234,8 +234,6 @@ __global__ __launch_bounds__(BYTES ? 1024 : 512) void ref_sample_kernel(const ui
     const bool real = site < len;
     const uint32_t nib = !real ? 15u : cls == 0 ? 8u : cls == 1 ? 4u : cls == 2 ? 2u : cls == 3 ? 1u : 15u;
     const uint32_t wave = b >> 6;
-    if (ref_codes)   // the same as a Paradis byte (A 136, G 72, C 40, T 24, N 240): the staged pack compares the records' bytes with it
-        ref_codes[site] = (uint8_t)(nib == 15u ? 0xF0u : nib << 4 | 8u);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const unsigned long long m = __ballot((nib >> (3 - p)) & 1u);
@@ -2388,7 +2386,7 @@ hipError_t launch_ref_sample(const DeviceSet &set, hipStream_t stream)
     hipLaunchKernelGGL(ref_sample_kernel<false>, dim3((unsigned)set.nchunks), dim3(512), 0, stream,
                        reinterpret_cast<const uint32_t *>(set.planes), nullptr, 0, (uint32_t)set.n, (uint32_t)set.len,
                        (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes, set.ref.hot_planes,
-                       set.ref.partials, nullptr, 0u, nullptr, set.ref.codes);
+                       set.ref.partials, nullptr, 0u, nullptr);
     return hipGetLastError();
 }
 
@@ -2398,7 +2396,7 @@ hipError_t launch_ref_sample_bytes(const uint8_t *d_codes, size_t row_stride, co
     const uint32_t samples = (uint32_t)std::min<size_t>(set.n, kRefSamples);
     hipLaunchKernelGGL(ref_sample_kernel<true>, dim3((unsigned)set.nchunks), dim3(1024), 0, stream, nullptr, d_codes, row_stride,
                        (uint32_t)set.n, (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, samples, set.ref.planes,
-                       set.ref.hot_planes, set.ref.partials, zero, (uint32_t)zero_words, first_bad, set.ref.codes);
+                       set.ref.hot_planes, set.ref.partials, zero, (uint32_t)zero_words, first_bad);
     return hipGetLastError();
 }
 

@@ -35,7 +35,6 @@ struct dst_ctx {
     uint64_t schedule_clock = 0;
     int variant = 0;
     int path = DST_PATH_AUTO;         // dst_set_path
-    double pack_staged_min_bytes = 1.0e9;   // dst_set_pack_staged: byte matrices from this size on take the staged pack
     double prep_min_work = 2.0e10;    // dst_set_prep_threshold: site comparisons below which DST_PATH_AUTO stays dense unasked
     int last_path = DST_PATH_DENSE;   // what the most recent run used
     // consensus path: tables, counters and scratch shared by the two sets

@@ -66,7 +66,6 @@ struct ConsensusRef {             // the reference sequence, sampled from the se
     uint4 *planes = nullptr;      // [4][nchunks] A,G,C,T planes of it (chunk-packed like the records'); N past len
     uint4 *hot_planes = nullptr;  // [nchunks] bit = 1: a hot site (kHotPermille), handed to the dense kernels by the hybrid path
     uint32_t *hot_sites = nullptr;  // [n_hot] the hot sites, ascending
-    uint8_t *codes = nullptr;       // [nchunks * 128] the reference as Paradis codes (A, G, C, T or N; N past the end): what the staged pack compares bytes with
     uint32_t *partials = nullptr;   // [nchunks][2][8] every chunk's two shares of `stats` (summed by hot_list_kernel)
     // device: {known sites, sum of deviants, sum of deviants^2, sample size, hot sites, known hot sites,
     //          sum of deviants over the cold sites, sum of deviants^2 over the cold sites}
@@ -326,9 +325,6 @@ struct PackLists {
     uint32_t *cnt_run, *run_cold, *run_hot;
     // the base planes of a chunk that is inline in its slot are not stored (DeviceSet::planes_deferred)
     int defer_planes;
-    // [nchunks * 128] the reference as codes: the pack takes the staged form (pack_kernel<8>, pack_chunk_sparse); NULL: the
-    // plain one (what dst_set_pack_staged decides; rows off 16-byte boundaries always take the plain one)
-    const uint8_t *ref_codes;
 };
 // a slot that holds every difference of its (record, chunk): not a chunk of N (flag 0x100), at most kSlotEntries of them
 __host__ __device__ inline bool slot_is_inline(uint32_t word0) { return !(word0 & 0x100u) && (word0 & 0xFFu) <= kSlotEntries; }

@@ -59,125 +59,9 @@ __device__ __forceinline__ void derive_planes(uint32_t A, uint32_t G, uint32_t C
     X0 = K & (G | T);
 }
 
-// A chunk of a set that stays near its reference sequence, without the bit gather.  The block's bytes are in LDS
-// (pack_kernel<8> stages them: a row's KiB per load instruction); a lane compares its (record, chunk)'s 32 words with the
-// reference's and looks byte by byte only at the words that differ — code checked, a difference in the base bits becomes a
-// slot entry.  Most chunks differ nowhere (0.25 differences per chunk at 50,000 x 30,000), a wave's longest lane has two or
-// three words to look at.  Handles a chunk that is inline in its slot (planes deferred: nothing but the slot is stored) and,
-// for sets that look for run chunks, a chunk of N (planes of all ones: no gather); false = not one of those (more
-// differences than a slot holds, an invalid byte in a chunk of N): the caller goes the long way, from the top.
-// Same slots, counters and first invalid byte as the long way (tests/test_gpu_deferred_planes.py and the fuzz sweep run
-// both forms against each other and the oracle).
-__device__ __forceinline__ bool pack_chunk_sparse(const uint4 *mine, const uint32_t *refw, const uint32_t *hotw, uint32_t site0,
-                                                  uint32_t len, uint32_t s, uint32_t c, uint32_t nchunks, uint32_t npad,
-                                                  const PackLists &lists, uint4 *__restrict__ planes,
-                                                  unsigned long long *__restrict__ first_bad)
-{
-    uint32_t m = 0, all = 0xFFFFFFFFu;   // m: word w differs from the reference's (bit 31 - w); all: AND of the bytes
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint4 v = mine[k], r = reinterpret_cast<const uint4 *>(refw)[k];
-        m = m << 1 | (v.x != r.x ? 1u : 0u);
-        m = m << 1 | (v.y != r.y ? 1u : 0u);
-        m = m << 1 | (v.z != r.z ? 1u : 0u);
-        m = m << 1 | (v.w != r.w ? 1u : 0u);
-        all &= v.x & v.y & v.z & v.w;
-    }
-    uint32_t sl[4] = {0, 0, 0, 0};
-    if (m != 0) {
-        const uint32_t *xw_lds = reinterpret_cast<const uint32_t *>(mine);
-        const bool all_n = (all & 0xF0F0F0F0u) == 0xF0F0F0F0u;
-        if (all_n && lists.cnt_run) {
-            // 128 sites of N, - or ? (0xF0, 0xF4, 0xF2 are the codes with all four base bits): a run chunk wherever the
-            // reference has a base — as in pack_kernel, but the planes are known without looking
-            uint32_t badw = 0;
-#pragma unroll
-            for (int w = 0; w < 32; ++w) {
-                const uint32_t x = xw_lds[w];
-                badw |= (x & 0x09090909u) | (x & (x << 1) & 0x04040404u);
-            }
-            if (badw)
-                return false;
-            const uint4 rA = lists.ref_planes[c], rG = lists.ref_planes[nchunks + c], rC = lists.ref_planes[2 * (size_t)nchunks + c],
-                        rT = lists.ref_planes[3 * (size_t)nchunks + c];
-            const uint32_t dw[4] = {~(rA.x & rG.x & rC.x & rT.x), ~(rA.y & rG.y & rC.y & rT.y), ~(rA.z & rG.z & rC.z & rT.z),
-                                    ~(rA.w & rG.w & rC.w & rT.w)};
-            uint32_t cold = 0, hot = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                cold += __builtin_popcount(dw[w] & ~hotw[w]);
-                hot += __builtin_popcount(dw[w] & hotw[w]);
-            }
-            if (cold + hot) {
-                atomicAdd(&lists.cnt_run[s], 1u);
-                if (cold)
-                    atomicAdd(&lists.run_cold[s], cold);
-                if (hot)
-                    atomicAdd(&lists.run_hot[s], hot);
-                sl[0] = min(cold + hot, 255u) | 0x100u;
-                const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-#pragma unroll
-                for (int p = 0; p <= PL_T; ++p)   // (not inline in its slot: stored)
-                    planes[((size_t)p * nchunks + c) * npad + s] = ones;
-            }
-        } else {
-            uint32_t k = 0, cold = 0, hot = 0, bad_at = 0xFFFFFFFFu;
-            while (m) {
-                const uint32_t w = (uint32_t)__builtin_clz(m);
-                m &= ~(0x80000000u >> w);
-                const uint32_t xw = xw_lds[w], rw = refw[w], hw = hotw[w >> 3] >> ((w & 7u) * 4u);
-#pragma unroll
-                for (uint32_t b = 0; b < 4; ++b) {
-                    const uint32_t code = (xw >> (8u * b)) & 0xFFu, rcode = (rw >> (8u * b)) & 0xFFu;
-                    if (code == rcode)
-                        continue;
-                    // the 17 codes of src/encoding.rs: one base bit -> low nibble 8; two or three -> 0; all four -> 0, 4 or 2
-                    const uint32_t nib = code >> 4, low = code & 15u, nb = (uint32_t)__builtin_popcount(nib);
-                    const bool ok = nb == 1 ? low == 8u : nb == 4 ? (low == 0u || low == 4u || low == 2u) : (nb != 0 && low == 0u);
-                    if (!ok && bad_at == 0xFFFFFFFFu)
-                        bad_at = 4u * w + b;
-                    const uint32_t rnib = rcode >> 4;
-                    if (nib != rnib) {
-                        const uint32_t is_hot = (hw >> b) & 1u;
-                        cold += 1u - is_hot;
-                        hot += is_hot;
-                        if (k < kSlotEntries) {
-                            const uint32_t cls = rnib == 8 ? 0u : rnib == 4 ? 1u : rnib == 2 ? 2u : rnib == 1 ? 3u : 4u;
-                            const uint32_t e = (4u * w + b) | cls << 7 | nib << 10 | is_hot << 14;
-                            ++k;   // halfword k of the slot
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j)
-                                sl[j] |= (k >> 1) == j ? e << (16u * (k & 1u)) : 0u;
-                        }
-                    }
-                }
-                if (cold + hot > kSlotEntries)
-                    return false;
-            }
-            sl[0] |= cold + hot;
-            if (cold + hot) {
-                atomicAdd(&lists.cnt_cold[s], cold);
-                if (hot)
-                    atomicAdd(&lists.cnt_hot[s], hot);
-            }
-            if (bad_at != 0xFFFFFFFFu)
-                atomicMin(first_bad, (unsigned long long)s * len + site0 + bad_at);
-        }
-    }
-    lists.slots[(size_t)c * npad + s] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
-    return true;
-}
-
 // One thread = one (record, 128-site chunk).  Lanes run along records, so the eight 16-byte
 // plane stores of a wave are 1 KiB contiguous each; every lane reads its own 128-byte line.
 // Sites >= len and records >= n are filled with N (0xF0): N contributes nothing to any tally.
-// CW = 8, the staged form (dst_set_pack_staged: big sets whose planes are deferred, rows on 16-byte boundaries): a wave = 8
-// records x 8 chunks, a block = 32 records x 1 KiB of each.  The block's bytes come in a ROW's KiB per load instruction —
-// what a wave's load instruction reads of one row sets the read rate (tools/ubench/read_rate.hip: 4.8 against 3.9 TB/s),
-// not what a block reads of it — and wait in LDS for the lanes that own the chunks, which take the short way
-// (pack_chunk_sparse) wherever they can: 0.42 -> 0.38 ms at 50,000 x 30,000.  Below ~0.5 GB the 37 KB of LDS and the barrier
-// per block cost more than that (10,000 x 30,000: 0.095 -> 0.108 ms): CW = 1 there.
-template <int CW>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ codes,
                                                    size_t row_stride, uint32_t n, uint32_t len,
                                                    uint32_t nchunks, uint32_t npad,
@@ -186,38 +70,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ c
                                                    int aligned16, PackLists lists, uint32_t rec_first, uint32_t rec_last)
 {
     // records [rec_first, rec_last): the whole padded set, or one rank's share of it (dst_upload_shared)
-    constexpr uint32_t RW = 64u / CW, kRowWords = 8u * 36u + 4u;   // LDS: 144 bytes per chunk, 1,168 per record
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t s = rec_first + (blockIdx.y * 4u + wave) * RW + lane / CW;
-    const uint32_t c = blockIdx.x * CW + lane % CW;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[CW == 8 ? 32u * kRowWords : 4u], refw[CW == 8 ? 256 : 4], hotw[CW == 8 ? 32 : 4];
-    bool sparse = false;
-    if constexpr (CW == 8) {
-        sparse = blockIdx.x * 1024u + 1024u <= len && lists.stats[1] <= lists.max_dev_sum;   // (the same for the whole block)
-        if (sparse) {
-            const uint32_t rec0 = rec_first + blockIdx.y * 32u + wave * 8u, live = min(n, rec_last);
-            uint4 v[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)   // (a clamped record: no predicated loads)
-                v[k] = *reinterpret_cast<const uint4 *>(codes + (size_t)min(rec0 + k, live - 1u) * row_stride + blockIdx.x * 1024u + lane * 16u);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                *reinterpret_cast<uint4 *>(&stage[(wave * 8u + k) * kRowWords + (lane >> 3) * 36u + (lane & 7u) * 4u]) = v[k];
-            refw[threadIdx.x] = reinterpret_cast<const uint32_t *>(lists.ref_codes)[blockIdx.x * 256u + threadIdx.x];
-            if (threadIdx.x < 32u)
-                hotw[threadIdx.x] = reinterpret_cast<const uint32_t *>(lists.hot_planes)[blockIdx.x * 32u + threadIdx.x];
-            __syncthreads();
-        }
-    }
-    if (s >= rec_last || c >= nchunks)
+    const uint32_t s = rec_first + blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (s >= rec_last)
         return;
-    if constexpr (CW == 8) {
-        if (sparse && s < n &&
-            pack_chunk_sparse(reinterpret_cast<const uint4 *>(&stage[(wave * 8u + lane / 8u) * kRowWords + (lane & 7u) * 36u]),
-                              &refw[(lane & 7u) * 32u], &hotw[(lane & 7u) * 4u], c * kChunkSites, len, s, c, nchunks, npad, lists, planes,
-                              first_bad))
-            return;
-    }
     uint32_t out[PL_COUNT][4];
 #pragma unroll
     for (int p = 0; p < PL_COUNT; ++p)
@@ -995,15 +851,8 @@ hipError_t launch_pack(const uint8_t *d_codes, size_t row_stride, const DeviceSe
     // bit 0: every row starts on a 16-byte boundary; bit 1: the matrix itself starts on a 4-byte boundary
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_codes) % 16 == 0) && (row_stride % 16 == 0) ? 1 : 0) |
                           (reinterpret_cast<uintptr_t>(d_codes) % 4 == 0 ? 2 : 0);
-    if (lists && lists->defer_planes && lists->ref_codes && (aligned16 & 1)) {
-        dim3 grid8((unsigned)((set.nchunks + 7) / 8), (unsigned)((last - first + 31) / 32));
-        hipLaunchKernelGGL(pack_kernel<8>, grid8, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
-                           (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
-                           d_first_bad, aligned16, *lists, first, last);
-        return hipGetLastError();
-    }
     dim3 grid((unsigned)set.nchunks, (unsigned)((last - first + 255) / 256));
-    hipLaunchKernelGGL(pack_kernel<1>, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_codes, row_stride, (uint32_t)set.n,
                        (uint32_t)set.len, (uint32_t)set.nchunks, (uint32_t)set.npad, set.planes,
                        d_first_bad, aligned16, lists ? *lists : none, first, last);
     return hipGetLastError();

@@ -131,7 +131,6 @@ extern "C" int dst_upload_shared(dst_comm *comm, int slot, const void *d_codes_v
     pl.cnt_hot = s.rec.pre_hot;
     pl.slots = s.rec.pre_slots;
     pl.defer_planes = planes_deferred_by_pack() ? 1 : 0;   // (a partial set runs on the consensus path only: nothing ever reads them)
-    pl.ref_codes = pl.defer_planes && (double)(rec_end - rec_begin) * (double)len >= ctx->pack_staged_min_bytes ? s.ref.codes : nullptr;
     rc = timer_begin(ctx, 1, stream);
     if (rc)
         return rc;

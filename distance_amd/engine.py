@@ -166,10 +166,6 @@ class Engine:
         self._check(self._lib.dst_run_records(self._h, slot, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
-    def set_pack_staged(self, min_bytes: float):
-        """byte matrices of min_bytes and more take the staged form of the pack kernel (dst_set_pack_staged; default 1e9)"""
-        self._check(self._lib.dst_set_pack_staged(self._h, float(min_bytes)))
-
     def planes_stored(self, slot: int = 0) -> bool:
         """False while the upload has deferred the set's bit-planes (a set prepared for the consensus path: dst_planes_stored)"""
         v = C.c_int()

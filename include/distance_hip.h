@@ -128,10 +128,6 @@ int dst_set_path(dst_ctx *ctx, int path);
  * (DESIGN.md 3b'') — and how many list entries that removed.  0 when the set has none, too many (more than a third of the
  * records), or its lists were not built by the upload's fused preparation.  Diagnostic; the results do not depend on it. */
 int dst_run_records(const dst_ctx *ctx, int slot, uint64_t *run_records, uint64_t *entries_removed);
-/* Tuning (like dst_set_variant): byte matrices of min_bytes and more — rows on 16-byte boundaries, a set prepared for the
- * consensus path — are packed by the staged form of the pack kernel (a block's bytes through LDS, a row's KiB per load
- * instruction: 10 % faster at 1.5 GB, slower below ~0.5 GB).  Default 1e9; 0: always.  The results do not depend on it. */
-int dst_set_pack_staged(dst_ctx *ctx, double min_bytes);
 /* *stored = 1 when the bit-planes of every (record, 128-site chunk) of the set are in HBM; 0 while the upload has deferred them: a
  * set prepared for the consensus path keeps, per chunk, its differences from the set's reference sequence (what that path
  * reads), and the planes of a chunk are written only if it does not fit that form — the rest is written, from the

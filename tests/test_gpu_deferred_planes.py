@@ -128,74 +128,3 @@ def test_a_diverse_set_keeps_its_planes():
         assert eng.planes_stored(0)
         i, j = 17, 333
         assert int(eng.run_square("n_high", i, i + 1)[j - i - 1]) == oracle.pair_distance("n_high", codes[i], codes[j])
-
-
-# ---- the staged form of the pack (dst_set_pack_staged; pack_kernel<8>, pack_chunk_sparse): big sets take it by default,
-# ---- here every set whose rows lie on 16-byte boundaries does
-@pytest.mark.parametrize("n,L", [(2_000, 4_992), (1_100, 3_328), (300, 1_024), (70, 12_304)])
-def test_the_staged_pack_leaves_what_the_plain_one_leaves(n, L):
-    codes = mixed_alignment(n, L, 81)
-    rows = sorted({0, 3, 4, 5, n // 2, n - 2})
-    want, want_counts, want_cons, _ = dense_engine_results(codes, ALL, rows)
-    res = {}
-    for staged in (False, True):
-        with da.Engine(0) as eng:
-            eng.set_prep_threshold(0)
-            eng.set_pack_staged(0.0 if staged else 1e30)
-            eng.upload(0, codes)
-            assert not eng.planes_stored(0)
-            eng.set_path("consensus")
-            cons = {(m, r): eng.run_square(m, r, r + 1) for m in ALL for r in rows}
-            counts = eng.base_counts(0)
-            runs = eng.run_records(0)
-            eng.set_path("hybrid")
-            hyb = {r: eng.run_square("k80", r, r + 1) for r in rows}
-            eng.set_path("dense")
-            dense = {(m, r): eng.run_square(m, r, r + 1) for m in ALL for r in rows}
-            assert eng.planes_stored(0)
-            res[staged] = (cons, counts, runs, hyb, dense, eng.consensus())
-    for staged in (False, True):
-        cons, counts, runs, hyb, dense, consensus = res[staged]
-        for key in want:
-            assert np.array_equal(cons[key], want[key], equal_nan=True), (staged, key)
-            assert np.array_equal(dense[key], want[key], equal_nan=True), (staged, key)
-        for r in rows:
-            assert np.array_equal(hyb[r], want[("k80", r)], equal_nan=True), (staged, r)
-        assert np.array_equal(counts, want_counts) and np.array_equal(consensus, want_cons), staged
-    assert res[False][2] == res[True][2]          # the same run records
-    rng = np.random.default_rng(7)
-    with da.Engine(0) as eng:
-        eng.set_prep_threshold(0)
-        eng.set_pack_staged(0.0)
-        eng.upload(0, codes)
-        eng.set_path("consensus")
-        for _ in range(20):
-            i = rows[int(rng.integers(0, len(rows)))]
-            j = int(rng.integers(i + 1, n))
-            assert int(eng.run_square("n_high", i, i + 1)[j - i - 1]) == oracle.pair_distance("n_high", codes[i], codes[j])
-            assert abs(eng.run_square("tn93", i, i + 1)[j - i - 1] - oracle.pair_distance("tn93", codes[i], codes[j])) <= 1e-12 or \
-                np.isnan(oracle.pair_distance("tn93", codes[i], codes[j]))
-
-
-def test_the_staged_pack_reports_the_first_invalid_byte():
-    n, L = 700, 2_048
-    base = mixed_alignment(n, L, 82)
-    valid = {136, 72, 40, 24, 192, 160, 144, 96, 80, 48, 224, 176, 208, 112, 240, 244, 242}
-    bad_values = [b for b in range(256) if b not in valid]
-    with da.Engine(0) as eng:
-        eng.set_prep_threshold(0)
-        eng.set_pack_staged(0.0)
-        for k, b in enumerate(bad_values[::7]):
-            codes = base.copy()
-            r, site = 5 + k, 100 + 37 * k          # rows 5.. include a record with runs of N / dense patches now and then
-            codes[r, site] = b
-            codes[n - 1, L - 1] = 0                # a later one: the first is what is reported
-            with pytest.raises(da.DistanceError) as ei:
-                eng.upload(0, codes)
-            assert ei.value.status == 3 and f"record {r} at site {site}" in ei.value.message, (b, ei.value.message)
-        codes = base.copy()
-        codes[3, 700] = 0xF1                       # record 3 is nothing but N: an invalid byte inside a chunk of N
-        with pytest.raises(da.DistanceError) as ei:
-            eng.upload(0, codes)
-        assert "record 3 at site 700" in ei.value.message
-        eng.upload(0, base)                        # and the clean set goes through
